@@ -1,0 +1,160 @@
+"""ctypes loader for the CPU oracle (librtdm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY -- parity unpinned, see oracle/rtdm_oracle.h.  Importable from
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never from the product
+package (rt-depth-map_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "librtdm_oracle.so")
+
+
+class BMParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "preFilterCap", "blockSize", "minDisparity", "numDisparities", "textureThreshold",
+        "uniquenessRatio", "speckleWindowSize", "speckleRange", "disp12MaxDiff")] + [
+        ("roi1", C.c_int * 4), ("roi2", C.c_int * 4)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in srcs)):
+        return _SO
+    subprocess.check_call(["make", "-s", "-C", _HERE, "-B"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        u8p, i16p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_int16), C.POINTER(C.c_int32)
+        L.orc_prefilter_xsobel.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t, C.c_int]
+        L.orc_prefilter_xsobel.restype = None
+        L.orc_bm_compute.argtypes = [C.POINTER(BMParams), u8p, C.c_size_t, u8p, C.c_size_t, C.c_int,
+                                     C.c_int, i16p, C.c_size_t, C.c_int]
+        L.orc_bm_compute.restype = C.c_int
+        L.orc_bm_valid_rect.argtypes = [C.POINTER(BMParams), C.c_int, C.c_int, C.POINTER(C.c_int * 4)]
+        L.orc_bm_valid_rect.restype = C.c_int
+        L.orc_bm_search.argtypes = [C.POINTER(BMParams), u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, i16p, C.c_size_t, i32p, C.c_size_t]
+        L.orc_bm_search.restype = None
+        L.orc_validate_disparity.argtypes = [i16p, C.c_size_t, i32p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                             C.c_int, C.c_int]
+        L.orc_validate_disparity.restype = None
+        L.orc_filter_speckles.argtypes = [i16p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_filter_speckles.restype = None
+        L.orc_ellipse_element.argtypes = [C.c_int, C.c_int, u8p]
+        L.orc_ellipse_element.restype = None
+        for n in ("orc_erode", "orc_dilate"):
+            getattr(L, n).argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
+            getattr(L, n).restype = None
+        L.orc_morph_open_close.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int]
+        L.orc_morph_open_close.restype = None
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def make_params(preFilterCap=31, blockSize=13, minDisparity=0, numDisparities=64, textureThreshold=10,
+                uniquenessRatio=10, speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1,
+                roi1=None, roi2=None):
+    """Defaults = the reference's literals at main.cpp:134-135 (numDisparities from BASELINE)."""
+    p = BMParams(preFilterCap, blockSize, minDisparity, numDisparities, textureThreshold,
+                 uniquenessRatio, speckleWindowSize, speckleRange, disp12MaxDiff)
+    p.roi1 = (C.c_int * 4)(*(roi1 or (0, 0, 0, 0)))
+    p.roi2 = (C.c_int * 4)(*(roi2 or (0, 0, 0, 0)))
+    return p
+
+
+def prefilter_xsobel(img, cap):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    H, W = img.shape
+    out = np.empty_like(img)
+    lib().orc_prefilter_xsobel(_p(img, C.c_uint8), W, W, H, _p(out, C.c_uint8), W, cap)
+    return out
+
+
+def bm_compute(left, right, nthreads=1, **kw):
+    """left/right: 2-D uint8 arrays (any row stride).  Returns int16 HxW disparity (x16)."""
+    assert left.dtype == np.uint8 and right.dtype == np.uint8 and left.shape == right.shape
+    assert left.strides[1] == 1 and right.strides[1] == 1
+    H, W = left.shape
+    p = kw.pop("params", None) or make_params(**kw)
+    disp = np.empty((H, W), np.int16)
+    rc = lib().orc_bm_compute(C.byref(p), _p(left, C.c_uint8), left.strides[0], _p(right, C.c_uint8),
+                              right.strides[0], W, H, _p(disp, C.c_int16), W * 2, nthreads)
+    if rc != 0:
+        raise ValueError("orc_bm_compute failed: %d" % rc)
+    return disp
+
+
+def bm_search(lp, rp, row0, row1, **kw):
+    lp = np.ascontiguousarray(lp, np.uint8); rp = np.ascontiguousarray(rp, np.uint8)
+    H, W = lp.shape
+    p = kw.pop("params", None) or make_params(**kw)
+    fil = (p.minDisparity - 1) * 16
+    disp = np.full((H, W), fil, np.int16)
+    cost = np.zeros((H, W), np.int32)
+    lib().orc_bm_search(C.byref(p), _p(lp, C.c_uint8), W, _p(rp, C.c_uint8), W, W, H, row0, row1,
+                        _p(disp, C.c_int16), W, _p(cost, C.c_int32), W)
+    return disp, cost
+
+
+def valid_rect(W, H, **kw):
+    p = kw.pop("params", None) or make_params(**kw)
+    r = (C.c_int * 4)()
+    ok = lib().orc_bm_valid_rect(C.byref(p), W, H, C.byref(r))
+    return tuple(r) if ok else None
+
+
+def validate_disparity(disp, cost, minD, numD, disp12MaxDiff):
+    disp = np.ascontiguousarray(disp, np.int16).copy(); cost = np.ascontiguousarray(cost, np.int32)
+    H, W = disp.shape
+    lib().orc_validate_disparity(_p(disp, C.c_int16), W, _p(cost, C.c_int32), W, W, H, minD, numD, disp12MaxDiff)
+    return disp
+
+
+def filter_speckles(disp, newVal, maxSpeckleSize, maxDiff):
+    disp = np.ascontiguousarray(disp, np.int16).copy()
+    H, W = disp.shape
+    lib().orc_filter_speckles(_p(disp, C.c_int16), W, W, H, newVal, maxSpeckleSize, maxDiff)
+    return disp
+
+
+def ellipse_element(kw=10, kh=10):
+    e = np.zeros((kh, kw), np.uint8)
+    lib().orc_ellipse_element(kw, kh, _p(e, C.c_uint8))
+    return e
+
+
+def erode(img, kw=10, kh=10):
+    img = np.ascontiguousarray(img, np.uint8); out = np.empty_like(img); H, W = img.shape
+    lib().orc_erode(_p(img, C.c_uint8), W, _p(out, C.c_uint8), W, W, H, kw, kh)
+    return out
+
+
+def dilate(img, kw=10, kh=10):
+    img = np.ascontiguousarray(img, np.uint8); out = np.empty_like(img); H, W = img.shape
+    lib().orc_dilate(_p(img, C.c_uint8), W, _p(out, C.c_uint8), W, W, H, kw, kh)
+    return out
+
+
+def morph_open_close(img):
+    img = np.ascontiguousarray(img, np.uint8); out = np.empty_like(img); H, W = img.shape
+    lib().orc_morph_open_close(_p(img, C.c_uint8), W, _p(out, C.c_uint8), W, W, H)
+    return out

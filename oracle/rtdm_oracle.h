@@ -1,0 +1,97 @@
+/*
+ * rtdm_oracle.h -- CPU oracle for the rt-depth-map block-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * product path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the HIP library (librtdm_hip.so)
+ * never links, loads or calls it.
+ *
+ * PARITY UNPINNED.  The reference's hot path is a 48-line wrapper
+ * (/root/reference/stereo-matcher/bm-sw.cpp:12-38) that forwards to OpenCV's
+ * cv::StereoBM; the morphological filter (/root/reference/filter/mf-sw.cpp:19-28)
+ * forwards to cv::erode / cv::dilate.  OpenCV is an un-vendored, un-pinned
+ * system dependency (reference Makefile.include:18-23; era => OpenCV 3.1-3.2),
+ * it is absent from the build image, and the reference holds no tests, golden
+ * vectors or sample images.  This file therefore restates the *published*
+ * algorithm of OpenCV calib3d (stereobm.cpp: prefilterXSobel,
+ * findStereoCorrespondenceBM, getValidDisparityROI; stereosgbm.cpp:
+ * validateDisparity, filterSpeckles) and imgproc (getStructuringElement,
+ * erode, dilate), anchored on the reference's call sites:
+ *   - parameters and call order: bm-sw.cpp:16-25,35; main.cpp:134-135
+ *   - ROI forwarding:            bm-sw.cpp:40-48; estimator.cpp:54
+ *   - morphology sequence:       mf-sw.cpp:22-27; mf-sw.h:11-12
+ * It is cross-checked by an independent brute-force implementation
+ * (tests/bruteforce.py) and by known-answer properties (tests/test_oracle_*.py).
+ */
+#ifndef RTDM_ORACLE_H_
+#define RTDM_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Parameter block; field meaning follows cv::StereoBM as set by
+ * SWMatcherKonolige's constructor (bm-sw.cpp:16-25). */
+typedef struct orc_bm_params {
+    int preFilterCap;      /* 1..63                     (main.cpp:134 -> 31) */
+    int blockSize;         /* odd, 5..255, < min(W,H)   (main.cpp:134 -> 13) */
+    int minDisparity;      /*                           (main.cpp:134 -> 0)  */
+    int numDisparities;    /* > 0, multiple of 16       (cmdline-parser.cpp:22 -> 192) */
+    int textureThreshold;  /* >= 0                      (main.cpp:134 -> 10) */
+    int uniquenessRatio;   /* >= 0                      (main.cpp:135 -> 10) */
+    int speckleWindowSize; /* 0 disables                (main.cpp:135 -> 100) */
+    int speckleRange;      /* unscaled, in x16 units    (main.cpp:135 -> 32) */
+    int disp12MaxDiff;     /* < 0 disables              (main.cpp:135 -> 1)  */
+    int roi1[4];           /* x,y,w,h; w*h == 0 means "whole image" (setROI1, bm-sw.cpp:40-43) */
+    int roi2[4];           /* x,y,w,h; never set by the reference (estimator.cpp:55) */
+} orc_bm_params;
+
+enum {
+    ORC_OK = 0,
+    ORC_ERR_BAD_PARAM = -1,
+    ORC_ERR_BAD_SIZE = -2
+};
+
+/* X-Sobel prefilter (OpenCV prefilterXSobel): clip(sobel_x, -cap, cap) + cap. */
+void orc_prefilter_xsobel(const uint8_t* src, size_t sstep, int W, int H,
+                          uint8_t* dst, size_t dstep, int cap);
+
+/* Full StereoBM::compute pipeline: prefilter -> SAD search on the valid rows ->
+ * left-right check -> column masking -> speckle filter.  disp is 16SC1, fixed
+ * point x16, invalid = (minDisparity-1)*16.  nthreads > 1 stripes the rows. */
+int orc_bm_compute(const orc_bm_params* p, const uint8_t* L, size_t lstep,
+                   const uint8_t* R, size_t rstep, int W, int H,
+                   int16_t* disp, size_t dstep_bytes, int nthreads);
+
+/* Individual stages, exposed so that tests can gate them one by one. */
+int orc_bm_valid_rect(const orc_bm_params* p, int W, int H, int rect[4]);
+/* SAD search only, on already prefiltered images, rows [row0,row1); writes
+ * disp rows [row0,row1) for every column and cost (int32, same geometry). */
+void orc_bm_search(const orc_bm_params* p, const uint8_t* Lp, size_t lstep,
+                   const uint8_t* Rp, size_t rstep, int W, int H,
+                   int row0, int row1, int16_t* disp, size_t dstep_elems,
+                   int32_t* cost, size_t cstep_elems);
+void orc_validate_disparity(int16_t* disp, size_t dstep_elems, const int32_t* cost,
+                            size_t cstep_elems, int W, int rows, int minD, int numD,
+                            int disp12MaxDiff);
+void orc_filter_speckles(int16_t* disp, size_t dstep_elems, int W, int H, int newVal,
+                         int maxSpeckleSize, int maxDiff);
+
+/* Morphology (mf-sw.cpp:19-28).  Element = getStructuringElement(MORPH_ELLIPSE,
+ * Size(kw,kh)), anchor (kw/2, kh/2), constant border that never wins. */
+void orc_ellipse_element(int kw, int kh, uint8_t* elem /* kh*kw */);
+void orc_erode(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int W, int H,
+               int kw, int kh);
+void orc_dilate(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, int W, int H,
+                int kw, int kh);
+/* erode -> dilate -> dilate -> erode with the 10x10 ellipse (MORPH_FILTER_DX/DY). */
+void orc_morph_open_close(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep,
+                          int W, int H);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
