@@ -1,0 +1,137 @@
+/*
+ * rtdm.h -- C ABI of the MI355X stereo block-matching module (librtdm_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of wafgo/rt-depth-map: a HIPMatcher class that
+ * derives from the reference's BlockMatcher (include/stereo-matcher/stereo-matcher.h:13-19) and
+ * sits next to SWMatcherKonolige / HWMatcherDisparityCoprocessor calls exactly these entry points
+ * (the adapter is rt-depth-map_amd/host/bm-hip.{h,cpp}; INTEGRATION.md shows the three-line
+ * change to main.cpp:134 and the Makefile.build rule).  Plain C types only: no OpenCV, no torch.
+ *
+ * Every function returns RTDM_OK (0) or a negative rtdm_status; nothing throws or aborts.  The
+ * library has NO CPU fallback: without a usable HIP device every create call fails with
+ * RTDM_ERR_NO_DEVICE.
+ */
+#ifndef RTDM_H_
+#define RTDM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTDM_ABI_VERSION 1
+
+typedef enum rtdm_status {
+    RTDM_OK = 0,
+    RTDM_ERR_BAD_PARAM = -1,   /* what cv::StereoBM::compute rejects with cv::Exception */
+    RTDM_ERR_BAD_SIZE = -2,    /* frame larger than the handle was created for, bad pitch ... */
+    RTDM_ERR_NO_DEVICE = -3,
+    RTDM_ERR_HIP = -4,         /* a HIP runtime call failed; see rtdm_last_hip_error() */
+    RTDM_ERR_NOMEM = -5,
+    RTDM_ERR_UNSUPPORTED = -6, /* valid for OpenCV but outside what this build implements */
+    RTDM_ERR_NULL = -7
+} rtdm_status;
+
+/* Same nine knobs SWMatcherKonolige's constructor forwards to cv::StereoBM
+ * (stereo-matcher/bm-sw.cpp:16-25; literals at main.cpp:134-135).  preFilterType is XSOBEL,
+ * the cv::StereoBM default the reference never changes. */
+typedef struct rtdm_bm_params {
+    int preFilterCap;      /* 1..63 */
+    int blockSize;         /* odd, 5..255, smaller than min(width,height) */
+    int minDisparity;
+    int numDisparities;    /* > 0, multiple of 16 */
+    int textureThreshold;  /* >= 0 */
+    int uniquenessRatio;   /* >= 0 */
+    int speckleWindowSize; /* <= 0 disables the speckle filter */
+    int speckleRange;      /* compared unscaled against the x16 fixed-point disparities */
+    int disp12MaxDiff;     /* < 0 disables the left-right check */
+} rtdm_bm_params;
+
+typedef struct rtdm_bm rtdm_bm;       /* one matcher = one GPU + one HIP stream + its workspace */
+typedef struct rtdm_morph rtdm_morph; /* one morphological filter device */
+
+const char* rtdm_strerror(int status);
+const char* rtdm_last_hip_error(void);   /* text of the last failing HIP call on this thread */
+int rtdm_abi_version(void);
+int rtdm_device_count(int* count);
+/* Fills the reference's literals: cap 31, block 13, minD 0, texture 10, uniqueness 10,
+ * speckle 100/32, disp12MaxDiff 1 (main.cpp:134-135); numDisparities as given. */
+void rtdm_bm_default_params(rtdm_bm_params* p, int numDisparities);
+
+/* ---- BlockMatcher ------------------------------------------------------------------------
+ * rtdm_bm_create   <- SWMatcherKonolige::SWMatcherKonolige (bm-sw.cpp:12-26); like the FPGA
+ *                     matcher (bm-hw-ip.h:74) it is told the frame size up front and owns
+ *                     device buffers for max_batch frames of max_width x max_height.
+ * rtdm_bm_set_roi  <- SWMatcherKonolige::setROI1 / setROI2 (bm-sw.cpp:40-48); which = 1 | 2;
+ *                     a zero-area rectangle means "whole image", as in cv::StereoBM.
+ * rtdm_bm_compute  <- SWMatcherKonolige::compute (bm-sw.cpp:33-38): host 8UC1 left/right with
+ *                     arbitrary row pitch (the caller passes ROI views, estimator.cpp:33,36),
+ *                     host 16SC1 output, fixed point x16, invalid = (minDisparity-1)*16.
+ *                     Synchronous.
+ */
+int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, int max_batch,
+                   int device, rtdm_bm** out);
+void rtdm_bm_destroy(rtdm_bm* bm);
+int rtdm_bm_set_roi(rtdm_bm* bm, int which, int x, int y, int width, int height);
+int rtdm_bm_get_params(const rtdm_bm* bm, rtdm_bm_params* out);
+int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const uint8_t* right,
+                    size_t right_pitch, int width, int height, int16_t* disp, size_t disp_pitch);
+
+/* Batched stream of independent pairs (BASELINE config 4).  Device-resident variant: frame i
+ * of an image lives at base + i*frame_stride, rows `pitch` bytes apart; the work is enqueued on
+ * `hip_stream` (a hipStream_t, NULL = the matcher's own stream) and NOT synchronised.  n may
+ * exceed max_batch; it is processed in chunks. */
+int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint8_t* d_right,
+                           size_t pitch, size_t frame_stride, int width, int height,
+                           int16_t* d_disp, size_t disp_pitch, size_t disp_frame_stride,
+                           void* hip_stream);
+/* Host variant: contiguous frames in host memory, H2D / compute / D2H overlapped in chunks. */
+int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t* right,
+                          size_t pitch, size_t frame_stride, int width, int height,
+                          int16_t* disp, size_t disp_pitch, size_t disp_frame_stride);
+int rtdm_bm_synchronize(rtdm_bm* bm);
+
+/* Per-stage device timing with HIP events on the launching stream (bench.py's roofline leg).
+ * Stages: 0 prefilter, 1 SAD search, 2 left-right check, 3 speckle filter. */
+#define RTDM_STAGE_PREFILTER 0
+#define RTDM_STAGE_SEARCH 1
+#define RTDM_STAGE_LRCHECK 2
+#define RTDM_STAGE_SPECKLE 3
+#define RTDM_NUM_STAGES 4
+int rtdm_bm_set_profiling(rtdm_bm* bm, int enabled);
+int rtdm_bm_get_stage_time(rtdm_bm* bm, int stage, double* total_ms, long* launches, long* frames);
+int rtdm_bm_reset_stage_times(rtdm_bm* bm);
+/* Name of the SAD-search kernel variant the current parameters select ("generic_u16", ...). */
+const char* rtdm_bm_search_variant(const rtdm_bm* bm);
+
+/* ---- VideoFilterDevice (morphological open + close, 10x10 ellipse) -----------------------
+ * rtdm_morph_create      <- SWMorphologicalFilter::SWMorphologicalFilter (filter/mf-sw.cpp:10-17)
+ * rtdm_morph_in_buffer / _out_buffer
+ *                        <- VideoFilterDevice::getVideoInBuffer / getVideoOutBuffer
+ *                           (filter/filter.cpp:45-53): width*height bytes each, owned by the
+ *                           device object, here page-locked host memory.
+ * rtdm_morph_run         <- SWMorphologicalFilter::run (filter/mf-sw.cpp:19-28): erode, dilate,
+ *                           dilate, erode with MORPH_ELLIPSE 10x10 (mf-sw.h:11-12).  Synchronous.
+ */
+int rtdm_morph_create(int width, int height, int max_batch, int device, rtdm_morph** out);
+void rtdm_morph_destroy(rtdm_morph* mf);
+uint8_t* rtdm_morph_in_buffer(rtdm_morph* mf);
+uint8_t* rtdm_morph_out_buffer(rtdm_morph* mf);
+int rtdm_morph_run(rtdm_morph* mf, const uint8_t* in, size_t in_pitch, uint8_t* out,
+                   size_t out_pitch, int width, int height);
+int rtdm_morph_run_device(rtdm_morph* mf, int n, const uint8_t* d_in, size_t in_pitch,
+                          size_t in_frame_stride, uint8_t* d_out, size_t out_pitch,
+                          size_t out_frame_stride, int width, int height, void* hip_stream);
+
+/* ---- synthetic rectified-pair stream (stands in for stream/ + decoder/, which are out of
+ * scope): frame f of the stream uses seed + f; bit-identical to rt-depth-map_amd/synth.py. */
+int rtdm_synth_pairs_device(uint64_t seed, int first_frame, int n, int width, int height,
+                            int numDisparities, uint8_t* d_left, uint8_t* d_right, size_t pitch,
+                            size_t frame_stride, int device, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTDM_H_ */

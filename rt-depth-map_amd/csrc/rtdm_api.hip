@@ -1,0 +1,501 @@
+// rtdm_api.hip -- the C ABI declared in include/rtdm.h: handle management, parameter validation
+// (the checks cv::StereoBM::compute performs), geometry, staging copies and
+// the launch sequence  K1 prefilter -> K2 search -> K3 left-right check -> K4 speckle filter.
+// There is no CPU fallback anywhere in this file: every entry point needs a HIP device.
+#include "../../include/rtdm.h"
+#include "rtdm_kernels.h"
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rtdm;
+
+static thread_local std::string g_hip_err;
+
+#define HIPC(expr)                                                                               \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            g_hip_err = std::string(#expr) + ": " + hipGetErrorString(e_);                       \
+            return RTDM_ERR_HIP;                                                                 \
+        }                                                                                        \
+    } while (0)
+
+struct StageEvent { hipEvent_t a, b; int stage; int frames; };
+
+struct rtdm_bm {
+    rtdm_bm_params p;
+    int maxW, maxH, maxB, device;
+    int roi1[4], roi2[4];
+    hipStream_t stream;
+    size_t ppitch;                 // pitch of the internal 8-bit planes
+    uint8_t *dLp, *dRp;            // prefiltered planes   [maxB][maxH][ppitch]
+    uint8_t *dInL, *dInR;          // staging for the host entry points
+    int16_t* dOut;                 //                      [maxB][maxH][maxW]
+    int32_t *dCost, *dLabel, *dSize;
+    bool profiling;
+    std::vector<StageEvent> pending;
+    double stage_ms[RTDM_NUM_STAGES];
+    long stage_launches[RTDM_NUM_STAGES], stage_frames[RTDM_NUM_STAGES];
+    std::string variant;
+};
+
+struct rtdm_morph {
+    int W, H, maxB, device;
+    hipStream_t stream;
+    uint8_t *hIn, *hOut;           // page-locked host buffers handed to the application
+    uint8_t *dIn, *dOut, *dT0, *dT1;
+};
+
+extern "C" {
+
+const char* rtdm_strerror(int s)
+{
+    switch (s) {
+        case RTDM_OK: return "ok";
+        case RTDM_ERR_BAD_PARAM: return "invalid StereoBM parameter";
+        case RTDM_ERR_BAD_SIZE: return "invalid frame size or pitch";
+        case RTDM_ERR_NO_DEVICE: return "no usable HIP device (this library has no CPU fallback)";
+        case RTDM_ERR_HIP: return "HIP runtime error";
+        case RTDM_ERR_NOMEM: return "out of memory";
+        case RTDM_ERR_UNSUPPORTED: return "configuration not supported by this build";
+        case RTDM_ERR_NULL: return "null pointer";
+        default: return "unknown rtdm status";
+    }
+}
+
+const char* rtdm_last_hip_error(void) { return g_hip_err.c_str(); }
+int rtdm_abi_version(void) { return RTDM_ABI_VERSION; }
+
+int rtdm_device_count(int* count)
+{
+    if (!count) return RTDM_ERR_NULL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    return n > 0 ? RTDM_OK : RTDM_ERR_NO_DEVICE;
+}
+
+void rtdm_bm_default_params(rtdm_bm_params* p, int numDisparities)
+{
+    if (!p) return;
+    p->preFilterCap = 31; p->blockSize = 13; p->minDisparity = 0; p->numDisparities = numDisparities;
+    p->textureThreshold = 10; p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32;
+    p->disp12MaxDiff = 1;
+}
+
+static int validate_params(const rtdm_bm_params& p)
+{
+    if (p.preFilterCap < 1 || p.preFilterCap > 63) return RTDM_ERR_BAD_PARAM;
+    if (p.blockSize < 5 || p.blockSize > 255 || (p.blockSize & 1) == 0) return RTDM_ERR_BAD_PARAM;
+    if (p.numDisparities <= 0 || p.numDisparities % 16 != 0) return RTDM_ERR_BAD_PARAM;
+    if (p.textureThreshold < 0 || p.uniquenessRatio < 0) return RTDM_ERR_BAD_PARAM;
+    return RTDM_OK;
+}
+
+static int use_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return RTDM_ERR_NO_DEVICE;
+    if (device < 0 || device >= n) return RTDM_ERR_NO_DEVICE;
+    HIPC(hipSetDevice(device));
+    return RTDM_OK;
+}
+
+int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, int max_batch,
+                   int device, rtdm_bm** out)
+{
+    if (!params || !out) return RTDM_ERR_NULL;
+    *out = nullptr;
+    int rc = validate_params(*params);
+    if (rc) return rc;
+    if (max_width <= 0 || max_height <= 0 || max_batch <= 0 || max_width > 32767 || max_height > 32767)
+        return RTDM_ERR_BAD_SIZE;
+    if ((long)max_batch * max_width * max_height >= (1L << 31)) return RTDM_ERR_BAD_SIZE;
+    rc = use_device(device);
+    if (rc) return rc;
+    rtdm_bm* bm = new (std::nothrow) rtdm_bm();
+    if (!bm) return RTDM_ERR_NOMEM;
+    bm->p = *params; bm->maxW = max_width; bm->maxH = max_height; bm->maxB = max_batch; bm->device = device;
+    for (int i = 0; i < 4; ++i) bm->roi1[i] = bm->roi2[i] = 0;
+    bm->profiling = false;
+    for (int i = 0; i < RTDM_NUM_STAGES; ++i) { bm->stage_ms[i] = 0; bm->stage_launches[i] = 0; bm->stage_frames[i] = 0; }
+    bm->ppitch = ((size_t)max_width + 63) & ~(size_t)63;
+    const size_t plane = bm->ppitch * max_height * (size_t)max_batch;
+    const size_t px = (size_t)max_width * max_height * max_batch;
+    hipError_t e = hipStreamCreateWithFlags(&bm->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dLp, plane);
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dRp, plane);
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dInL, plane);
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dInR, plane);
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dOut, px * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dCost, px * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dLabel, px * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dSize, px * sizeof(int32_t));
+    if (e != hipSuccess) {
+        g_hip_err = std::string("rtdm_bm_create: ") + hipGetErrorString(e);
+        rtdm_bm_destroy(bm);
+        return e == hipErrorOutOfMemory ? RTDM_ERR_NOMEM : RTDM_ERR_HIP;
+    }
+    *out = bm;
+    return RTDM_OK;
+}
+
+void rtdm_bm_destroy(rtdm_bm* bm)
+{
+    if (!bm) return;
+    (void)hipSetDevice(bm->device);
+    if (bm->stream) (void)hipStreamSynchronize(bm->stream);
+    for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+    void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (bm->stream) (void)hipStreamDestroy(bm->stream);
+    delete bm;
+}
+
+int rtdm_bm_set_roi(rtdm_bm* bm, int which, int x, int y, int width, int height)
+{
+    if (!bm) return RTDM_ERR_NULL;
+    if (which != 1 && which != 2) return RTDM_ERR_BAD_PARAM;
+    int* r = which == 1 ? bm->roi1 : bm->roi2;
+    r[0] = x; r[1] = y; r[2] = width; r[3] = height;
+    return RTDM_OK;
+}
+
+int rtdm_bm_get_params(const rtdm_bm* bm, rtdm_bm_params* out)
+{
+    if (!bm || !out) return RTDM_ERR_NULL;
+    *out = bm->p;
+    return RTDM_OK;
+}
+
+// offsets, valid rectangle (getValidDisparityROI, clipped to the image and
+// to rows that have a full window).  Returns false when the whole frame is FILTERED.
+static bool make_geom(const rtdm_bm* bm, int W, int H, BMGeom* g)
+{
+    const rtdm_bm_params& p = bm->p;
+    g->W = W; g->H = H; g->D = p.numDisparities; g->minD = p.minDisparity;
+    g->w = p.blockSize; g->r = p.blockSize / 2;
+    g->cap = p.preFilterCap; g->tex = p.textureThreshold; g->uniq = p.uniquenessRatio;
+    g->lofs = std::max(g->D - 1 + g->minD, 0);
+    g->rofs = -std::min(g->D - 1 + g->minD, 0);
+    g->width1 = W - g->rofs - g->D + 1;
+    g->filtered = (g->minD - 1) * 16;
+    g->want_cost = p.disp12MaxDiff >= 0;
+    g->mask_cols = p.disp12MaxDiff < 0;
+    int r1[4] = {0, 0, W, H}, r2[4] = {0, 0, W, H};
+    if (bm->roi1[2] > 0 && bm->roi1[3] > 0) std::copy(bm->roi1, bm->roi1 + 4, r1);
+    if (bm->roi2[2] > 0 && bm->roi2[3] > 0) std::copy(bm->roi2, bm->roi2 + 4, r2);
+    const int maxD = g->minD + g->D - 1;
+    int xmin = std::max(r1[0], r2[0] + maxD) + g->r;
+    int xmax = std::min(r1[0] + r1[2], r2[0] + r2[2] - g->minD) - g->r;
+    int ymin = std::max(r1[1], r2[1]) + g->r;
+    int ymax = std::min(r1[1] + r1[3], r2[1] + r2[3]) - g->r;
+    xmin = std::max(xmin, 0); xmax = std::min(xmax, W);
+    ymin = std::max(ymin, g->r); ymax = std::min(ymax, H - g->r);
+    g->vx0 = xmin; g->vx1 = xmax; g->vy0 = ymin; g->vy1 = ymax;
+    if (g->lofs >= W || g->rofs >= W || g->width1 < 1) return false;
+    return xmax > xmin && ymax > ymin;
+}
+
+static void stage_begin(rtdm_bm* bm, int stage, int frames, hipStream_t s, StageEvent* ev)
+{
+    if (!bm->profiling) return;
+    ev->stage = stage; ev->frames = frames;
+    (void)hipEventCreate(&ev->a); (void)hipEventCreate(&ev->b);
+    (void)hipEventRecord(ev->a, s);
+}
+static void stage_end(rtdm_bm* bm, hipStream_t s, StageEvent* ev)
+{
+    if (!bm->profiling) return;
+    (void)hipEventRecord(ev->b, s);
+    bm->pending.push_back(*ev);
+}
+
+// One chunk (n <= maxB) of device-resident frames, enqueued on `s`.
+static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s)
+{
+    const rtdm_bm_params& p = bm->p;
+    BMGeom g;
+    const bool any = make_geom(bm, W, H, &g);
+    launch_fill16(disp, W, H, n, g.filtered, s);
+    if (!any) return RTDM_OK;
+    StageEvent ev;
+    const bool fast = fast_search_supported(g);
+    bool u16 = false;
+    if (!fast && !generic_search_supported(g, &u16)) return RTDM_ERR_UNSUPPORTED;
+    if (fast) {
+        bm->variant = "fast_qsad";
+        stage_begin(bm, RTDM_STAGE_SEARCH, n, s, &ev);
+        launch_search_fast(L, R, disp, bm->dCost, g, n, s);
+        stage_end(bm, s, &ev);
+    } else {
+        bm->variant = u16 ? "generic_u16" : "generic_u32";
+        Plane8W Lp{bm->dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{bm->dRp, bm->ppitch, bm->ppitch * (size_t)H};
+        stage_begin(bm, RTDM_STAGE_PREFILTER, n, s, &ev);
+        launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s);
+        stage_end(bm, s, &ev);
+        Plane8 Lpr{bm->dLp, Lp.pitch, Lp.frame}, Rpr{bm->dRp, Rp.pitch, Rp.frame};
+        stage_begin(bm, RTDM_STAGE_SEARCH, n, s, &ev);
+        launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s);
+        stage_end(bm, s, &ev);
+    }
+    if (p.disp12MaxDiff >= 0) {
+        stage_begin(bm, RTDM_STAGE_LRCHECK, n, s, &ev);
+        launch_lrcheck(disp, bm->dCost, g, p.disp12MaxDiff, n, s);
+        stage_end(bm, s, &ev);
+    }
+    if (p.speckleRange >= 0 && p.speckleWindowSize > 0) {
+        stage_begin(bm, RTDM_STAGE_SPECKLE, n, s, &ev);
+        launch_speckle(disp, bm->dLabel, bm->dSize, W, H, n, g.filtered, p.speckleWindowSize, p.speckleRange, s);
+        stage_end(bm, s, &ev);
+    }
+    HIPC(hipGetLastError());
+    return RTDM_OK;
+}
+
+static int check_frame(const rtdm_bm* bm, int W, int H)
+{
+    if (W <= 0 || H <= 0 || W > bm->maxW || H > bm->maxH) return RTDM_ERR_BAD_SIZE;
+    if (bm->p.blockSize >= std::min(W, H)) return RTDM_ERR_BAD_PARAM;   // cv::StereoBM::compute's check
+    return RTDM_OK;
+}
+
+int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint8_t* d_right,
+                           size_t pitch, size_t frame_stride, int width, int height,
+                           int16_t* d_disp, size_t disp_pitch, size_t disp_frame_stride, void* hip_stream)
+{
+    if (!bm || !d_left || !d_right || !d_disp) return RTDM_ERR_NULL;
+    if (n <= 0) return RTDM_ERR_BAD_SIZE;
+    int rc = check_frame(bm, width, height);
+    if (rc) return rc;
+    if (pitch < (size_t)width || disp_pitch < (size_t)width * 2 || (disp_pitch & 1) || (disp_frame_stride & 1))
+        return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(bm->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : bm->stream;
+    for (int i0 = 0; i0 < n; i0 += bm->maxB) {
+        const int m = std::min(bm->maxB, n - i0);
+        Plane8 L{d_left + (size_t)i0 * frame_stride, pitch, frame_stride};
+        Plane8 R{d_right + (size_t)i0 * frame_stride, pitch, frame_stride};
+        Plane16W O{d_disp + (size_t)i0 * (disp_frame_stride / 2), disp_pitch / 2, disp_frame_stride / 2};
+        rc = run_chunk(bm, m, L, R, width, height, O, s);
+        if (rc) return rc;
+    }
+    return RTDM_OK;
+}
+
+int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t* right,
+                          size_t pitch, size_t frame_stride, int width, int height,
+                          int16_t* disp, size_t disp_pitch, size_t disp_frame_stride)
+{
+    if (!bm || !left || !right || !disp) return RTDM_ERR_NULL;
+    if (n <= 0) return RTDM_ERR_BAD_SIZE;
+    int rc = check_frame(bm, width, height);
+    if (rc) return rc;
+    if (pitch < (size_t)width || disp_pitch < (size_t)width * 2) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(bm->device));
+    hipStream_t s = bm->stream;
+    const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
+    const size_t opitch = (size_t)width * 2, oframe = opitch * (size_t)height;
+    for (int i0 = 0; i0 < n; i0 += bm->maxB) {
+        const int m = std::min(bm->maxB, n - i0);
+        for (int i = 0; i < m; ++i) {
+            HIPC(hipMemcpy2DAsync(bm->dInL + i * dframe, dpitch, left + (size_t)(i0 + i) * frame_stride, pitch,
+                                  width, height, hipMemcpyHostToDevice, s));
+            HIPC(hipMemcpy2DAsync(bm->dInR + i * dframe, dpitch, right + (size_t)(i0 + i) * frame_stride, pitch,
+                                  width, height, hipMemcpyHostToDevice, s));
+        }
+        Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
+        Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
+        rc = run_chunk(bm, m, L, R, width, height, O, s);
+        if (rc) return rc;
+        for (int i = 0; i < m; ++i)
+            HIPC(hipMemcpy2DAsync((uint8_t*)disp + (size_t)(i0 + i) * disp_frame_stride, disp_pitch,
+                                  (uint8_t*)bm->dOut + i * oframe, opitch, opitch, height, hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));   // staging buffers are reused by the next chunk
+    }
+    return RTDM_OK;
+}
+
+int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const uint8_t* right,
+                    size_t right_pitch, int width, int height, int16_t* disp, size_t disp_pitch)
+{
+    if (!bm || !left || !right || !disp) return RTDM_ERR_NULL;
+    int rc = check_frame(bm, width, height);
+    if (rc) return rc;
+    if (left_pitch < (size_t)width || right_pitch < (size_t)width || disp_pitch < (size_t)width * 2)
+        return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(bm->device));
+    hipStream_t s = bm->stream;
+    const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
+    HIPC(hipMemcpy2DAsync(bm->dInL, dpitch, left, left_pitch, width, height, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpy2DAsync(bm->dInR, dpitch, right, right_pitch, width, height, hipMemcpyHostToDevice, s));
+    Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
+    Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
+    rc = run_chunk(bm, 1, L, R, width, height, O, s);
+    if (rc) return rc;
+    HIPC(hipMemcpy2DAsync(disp, disp_pitch, bm->dOut, (size_t)width * 2, (size_t)width * 2, height,
+                          hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    return RTDM_OK;
+}
+
+int rtdm_bm_synchronize(rtdm_bm* bm)
+{
+    if (!bm) return RTDM_ERR_NULL;
+    HIPC(hipSetDevice(bm->device));
+    HIPC(hipStreamSynchronize(bm->stream));
+    return RTDM_OK;
+}
+
+int rtdm_bm_set_profiling(rtdm_bm* bm, int enabled)
+{
+    if (!bm) return RTDM_ERR_NULL;
+    bm->profiling = enabled != 0;
+    return RTDM_OK;
+}
+
+static int drain_events(rtdm_bm* bm)
+{
+    for (auto& ev : bm->pending) {
+        HIPC(hipEventSynchronize(ev.b));
+        float ms = 0.f;
+        HIPC(hipEventElapsedTime(&ms, ev.a, ev.b));
+        bm->stage_ms[ev.stage] += ms;
+        bm->stage_launches[ev.stage] += 1;
+        bm->stage_frames[ev.stage] += ev.frames;
+        (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b);
+    }
+    bm->pending.clear();
+    return RTDM_OK;
+}
+
+int rtdm_bm_get_stage_time(rtdm_bm* bm, int stage, double* total_ms, long* launches, long* frames)
+{
+    if (!bm) return RTDM_ERR_NULL;
+    if (stage < 0 || stage >= RTDM_NUM_STAGES) return RTDM_ERR_BAD_PARAM;
+    HIPC(hipSetDevice(bm->device));
+    int rc = drain_events(bm);
+    if (rc) return rc;
+    if (total_ms) *total_ms = bm->stage_ms[stage];
+    if (launches) *launches = bm->stage_launches[stage];
+    if (frames) *frames = bm->stage_frames[stage];
+    return RTDM_OK;
+}
+
+int rtdm_bm_reset_stage_times(rtdm_bm* bm)
+{
+    if (!bm) return RTDM_ERR_NULL;
+    HIPC(hipSetDevice(bm->device));
+    int rc = drain_events(bm);
+    if (rc) return rc;
+    for (int i = 0; i < RTDM_NUM_STAGES; ++i) { bm->stage_ms[i] = 0; bm->stage_launches[i] = 0; bm->stage_frames[i] = 0; }
+    return RTDM_OK;
+}
+
+const char* rtdm_bm_search_variant(const rtdm_bm* bm) { return bm ? bm->variant.c_str() : ""; }
+
+// ---- VideoFilterDevice ---------------------------------------------------------------------
+int rtdm_morph_create(int width, int height, int max_batch, int device, rtdm_morph** out)
+{
+    if (!out) return RTDM_ERR_NULL;
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || max_batch <= 0) return RTDM_ERR_BAD_SIZE;
+    int rc = use_device(device);
+    if (rc) return rc;
+    rtdm_morph* mf = new (std::nothrow) rtdm_morph();
+    if (!mf) return RTDM_ERR_NOMEM;
+    mf->W = width; mf->H = height; mf->maxB = max_batch; mf->device = device;
+    const size_t px = (size_t)width * height, all = px * max_batch;
+    hipError_t e = hipStreamCreateWithFlags(&mf->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&mf->hIn, px, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&mf->hOut, px, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&mf->dIn, all);
+    if (e == hipSuccess) e = hipMalloc((void**)&mf->dOut, all);
+    if (e == hipSuccess) e = hipMalloc((void**)&mf->dT0, all);
+    if (e == hipSuccess) e = hipMalloc((void**)&mf->dT1, all);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("rtdm_morph_create: ") + hipGetErrorString(e);
+        rtdm_morph_destroy(mf);
+        return e == hipErrorOutOfMemory ? RTDM_ERR_NOMEM : RTDM_ERR_HIP;
+    }
+    *out = mf;
+    return RTDM_OK;
+}
+
+void rtdm_morph_destroy(rtdm_morph* mf)
+{
+    if (!mf) return;
+    (void)hipSetDevice(mf->device);
+    if (mf->stream) (void)hipStreamSynchronize(mf->stream);
+    if (mf->hIn) (void)hipHostFree(mf->hIn);
+    if (mf->hOut) (void)hipHostFree(mf->hOut);
+    void* bufs[] = {mf->dIn, mf->dOut, mf->dT0, mf->dT1};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (mf->stream) (void)hipStreamDestroy(mf->stream);
+    delete mf;
+}
+
+uint8_t* rtdm_morph_in_buffer(rtdm_morph* mf) { return mf ? mf->hIn : nullptr; }
+uint8_t* rtdm_morph_out_buffer(rtdm_morph* mf) { return mf ? mf->hOut : nullptr; }
+
+int rtdm_morph_run_device(rtdm_morph* mf, int n, const uint8_t* d_in, size_t in_pitch, size_t in_frame_stride,
+                          uint8_t* d_out, size_t out_pitch, size_t out_frame_stride, int width, int height,
+                          void* hip_stream)
+{
+    if (!mf || !d_in || !d_out) return RTDM_ERR_NULL;
+    if (n <= 0 || width <= 0 || height <= 0 || (size_t)width * height > (size_t)mf->W * mf->H) return RTDM_ERR_BAD_SIZE;
+    if (in_pitch < (size_t)width || out_pitch < (size_t)width) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(mf->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : mf->stream;
+    for (int i0 = 0; i0 < n; i0 += mf->maxB) {
+        const int m = std::min(mf->maxB, n - i0);
+        Plane8 in{d_in + (size_t)i0 * in_frame_stride, in_pitch, in_frame_stride};
+        Plane8W out{d_out + (size_t)i0 * out_frame_stride, out_pitch, out_frame_stride};
+        launch_morph_open_close(in, out, mf->dT0, mf->dT1, width, height, m, s);
+    }
+    HIPC(hipGetLastError());
+    return RTDM_OK;
+}
+
+int rtdm_morph_run(rtdm_morph* mf, const uint8_t* in, size_t in_pitch, uint8_t* out, size_t out_pitch,
+                   int width, int height)
+{
+    if (!mf || !in || !out) return RTDM_ERR_NULL;
+    if (width <= 0 || height <= 0 || (size_t)width * height > (size_t)mf->W * mf->H) return RTDM_ERR_BAD_SIZE;
+    if (in_pitch < (size_t)width || out_pitch < (size_t)width) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(mf->device));
+    hipStream_t s = mf->stream;
+    HIPC(hipMemcpy2DAsync(mf->dIn, width, in, in_pitch, width, height, hipMemcpyHostToDevice, s));
+    int rc = rtdm_morph_run_device(mf, 1, mf->dIn, width, (size_t)width * height, mf->dOut, width,
+                                   (size_t)width * height, width, height, s);
+    if (rc) return rc;
+    HIPC(hipMemcpy2DAsync(out, out_pitch, mf->dOut, width, width, height, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    return RTDM_OK;
+}
+
+// ---- synthetic stream ------------------------------------------------------------------------
+int rtdm_synth_pairs_device(uint64_t seed, int first_frame, int n, int width, int height, int numDisparities,
+                            uint8_t* d_left, uint8_t* d_right, size_t pitch, size_t frame_stride, int device,
+                            void* hip_stream)
+{
+    if (!d_left || !d_right) return RTDM_ERR_NULL;
+    if (n <= 0 || width <= 0 || height <= 0 || pitch < (size_t)width) return RTDM_ERR_BAD_SIZE;
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    void* scratch = nullptr;
+    HIPC(hipMalloc(&scratch, synth_scratch_bytes(n)));
+    Plane8W L{d_left, pitch, frame_stride}, R{d_right, pitch, frame_stride};
+    launch_synth(seed, first_frame, n, width, height, numDisparities, L, R, scratch, s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    HIPC(e);
+    return RTDM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+"""Host-side mirror of the reference's plugin interfaces, for tests and bench.py.
+
+``HIPMatcher`` mirrors ``BlockMatcher`` (include/stereo-matcher/stereo-matcher.h:13-19) with the
+constructor shape of ``SWMatcherKonolige`` (include/stereo-matcher/bm-sw.h:28-30):
+``compute(left, right) -> disp``, ``setROI1``, ``setROI2``.  ``HIPMorphologicalFilter`` mirrors
+``VideoFilterDevice`` (include/filter/filter.h:13-37): ``run``, ``getVideoInBuffer`` ...
+The C++ adapter that actually plugs into the reference is rt-depth-map_amd/host/bm-hip.{h,cpp}; both
+are thin shells over the same C ABI (include/rtdm.h).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import binding as B
+
+
+class HIPMatcher:
+    def __init__(self, roi1=None, roi2=None, preFilterCap=31, blockSize=13, minDisparity=0, textureThreshold=10,
+                 numOfDisparities=64, maxDisparity=None, uniquenessRatio=10, speckleWindowSize=100,
+                 speckleRange=32, disp12MaxDiff=1, width=1280, height=720, max_batch=1, device=0):
+        # roi1/roi2/maxDisparity are accepted and ignored, exactly like bm-sw.cpp:12-26
+        self._h = C.c_void_p()
+        self.params = B.make_params(preFilterCap, blockSize, minDisparity, numOfDisparities, textureThreshold,
+                                    uniquenessRatio, speckleWindowSize, speckleRange, disp12MaxDiff)
+        self.width, self.height, self.max_batch, self.device = width, height, max_batch, device
+        B.check(B.lib().rtdm_bm_create(C.byref(self.params), width, height, max_batch, device, C.byref(self._h)),
+                "rtdm_bm_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            B.lib().rtdm_bm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def setROI1(self, roi):
+        B.check(B.lib().rtdm_bm_set_roi(self._h, 1, *[int(v) for v in roi]), "rtdm_bm_set_roi")
+
+    def setROI2(self, roi):
+        B.check(B.lib().rtdm_bm_set_roi(self._h, 2, *[int(v) for v in roi]), "rtdm_bm_set_roi")
+
+    @property
+    def filtered(self):
+        return (self.params.minDisparity - 1) * 16
+
+    def compute(self, left, right):
+        """left/right: 2-D uint8 numpy arrays (row stride free, column stride 1) -> int16 HxW (x16)."""
+        assert left.dtype == np.uint8 and right.dtype == np.uint8 and left.shape == right.shape
+        assert left.ndim == 2 and left.strides[1] == 1 and right.strides[1] == 1
+        H, W = left.shape
+        disp = np.empty((H, W), np.int16)
+        B.check(B.lib().rtdm_bm_compute(self._h, left.ctypes.data, left.strides[0], right.ctypes.data,
+                                        right.strides[0], W, H, disp.ctypes.data, W * 2), "rtdm_bm_compute")
+        return disp
+
+    def compute_batch(self, left, right):
+        """left/right: uint8 [n, H, W] C-contiguous host arrays -> int16 [n, H, W]."""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        n, H, W = left.shape
+        disp = np.empty((n, H, W), np.int16)
+        B.check(B.lib().rtdm_bm_compute_batch(self._h, n, left.ctypes.data, right.ctypes.data, W, W * H, W, H,
+                                              disp.ctypes.data, W * 2, W * H * 2), "rtdm_bm_compute_batch")
+        return disp
+
+    def compute_device(self, d_left, d_right, d_disp, stream=None):
+        """torch CUDA tensors: uint8 [n,H,W] x2, int16 [n,H,W]; enqueued on ``stream`` (a raw
+        hipStream_t value, e.g. torch.cuda.current_stream().cuda_stream), not synchronised."""
+        n, H, W = d_left.shape
+        assert d_left.is_contiguous() and d_right.is_contiguous() and d_disp.is_contiguous()
+        B.check(B.lib().rtdm_bm_compute_device(self._h, n, d_left.data_ptr(), d_right.data_ptr(), W, W * H, W, H,
+                                               d_disp.data_ptr(), W * 2, W * H * 2, stream), "rtdm_bm_compute_device")
+
+    def synchronize(self):
+        B.check(B.lib().rtdm_bm_synchronize(self._h), "rtdm_bm_synchronize")
+
+    def set_profiling(self, on):
+        B.check(B.lib().rtdm_bm_set_profiling(self._h, int(bool(on))), "rtdm_bm_set_profiling")
+
+    def reset_stage_times(self):
+        B.check(B.lib().rtdm_bm_reset_stage_times(self._h), "rtdm_bm_reset_stage_times")
+
+    def stage_times(self):
+        out = {}
+        for i, name in enumerate(B.STAGES):
+            ms, nl, nf = C.c_double(), C.c_long(), C.c_long()
+            B.check(B.lib().rtdm_bm_get_stage_time(self._h, i, C.byref(ms), C.byref(nl), C.byref(nf)), "get_stage_time")
+            out[name] = dict(total_ms=ms.value, launches=nl.value, frames=nf.value)
+        return out
+
+    @property
+    def search_variant(self):
+        return B.lib().rtdm_bm_search_variant(self._h).decode()
+
+
+class HIPMorphologicalFilter:
+    """VideoFilterDevice (filter/filter.h:13-37) over rtdm_morph_*; ctor shape of mf-sw.cpp:10-17."""
+
+    def __init__(self, w, h, bpp=8, max_batch=1, device=0):
+        if bpp != 8:
+            raise ValueError("only 8 bpp masks are filtered (mf-sw.cpp is called with bpp=8, main.cpp:133)")
+        self._h = C.c_void_p()
+        self.img_width, self.img_height, self.img_bpp = w, h, bpp
+        B.check(B.lib().rtdm_morph_create(w, h, max_batch, device, C.byref(self._h)), "rtdm_morph_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            B.lib().rtdm_morph_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def getFrameSize(self):
+        return self.img_width * self.img_height * (self.img_bpp >> 3)
+
+    def _buf(self, ptr):
+        arr = (C.c_uint8 * self.getFrameSize()).from_address(ptr)
+        return np.frombuffer(arr, np.uint8).reshape(self.img_height, self.img_width)
+
+    def getVideoInBuffer(self):
+        return self._buf(B.lib().rtdm_morph_in_buffer(self._h))
+
+    def getVideoOutBuffer(self):
+        return self._buf(B.lib().rtdm_morph_out_buffer(self._h))
+
+    def run(self, inp, out=None):
+        assert inp.dtype == np.uint8 and inp.ndim == 2 and inp.strides[1] == 1
+        H, W = inp.shape
+        if out is None:
+            out = np.empty((H, W), np.uint8)
+        B.check(B.lib().rtdm_morph_run(self._h, inp.ctypes.data, inp.strides[0], out.ctypes.data, out.strides[0],
+                                       W, H), "rtdm_morph_run")
+        return out
+
+    def run_device(self, d_in, d_out, stream=None):
+        n, H, W = d_in.shape
+        B.check(B.lib().rtdm_morph_run_device(self._h, n, d_in.data_ptr(), W, W * H, d_out.data_ptr(), W, W * H,
+                                              W, H, stream), "rtdm_morph_run_device")
+
+
+def synth_pairs_device(d_left, d_right, first_frame, numDisparities, seed=None, device=0, stream=None):
+    """Fill torch uint8 [n,H,W] tensors with frames [first_frame, first_frame+n) of the stream."""
+    from . import synth
+    n, H, W = d_left.shape
+    B.check(B.lib().rtdm_synth_pairs_device(synth.STREAM_SEED if seed is None else seed, first_frame, n, W, H,
+                                            numDisparities, d_left.data_ptr(), d_right.data_ptr(), W, W * H,
+                                            device, stream), "rtdm_synth_pairs_device")

@@ -1,0 +1,72 @@
+"""No-GPU checks of the drop-in boundary: the library loads, exports every symbol that include/rtdm.h
+declares, reports errors the way the header says, and refuses to run without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, load
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "rtdm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rtdm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    B = load("binding")
+    L = C.CDLL(B.LIB_PATH)
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "librtdm_hip.so lacks " + n
+    assert sorted(B.EXPORTS) == names
+
+
+def test_abi_version_and_strerror():
+    B = load("binding")
+    L = B.lib()
+    assert L.rtdm_abi_version() == 1
+    assert L.rtdm_strerror(0) == b"ok"
+    assert b"no CPU fallback" in L.rtdm_strerror(-3)
+    p = B.BMParams()
+    L.rtdm_bm_default_params(C.byref(p), 192)
+    # main.cpp:134-135 literals
+    assert (p.preFilterCap, p.blockSize, p.minDisparity, p.textureThreshold, p.numDisparities, p.uniquenessRatio,
+            p.speckleWindowSize, p.speckleRange, p.disp12MaxDiff) == (31, 13, 0, 10, 192, 10, 100, 32, 1)
+
+
+def test_parameter_validation_precedes_device_use():
+    B = load("binding")
+    L = B.lib()
+    h = C.c_void_p()
+    for bad in (dict(numDisparities=20), dict(blockSize=8), dict(blockSize=3), dict(preFilterCap=0),
+                dict(preFilterCap=64), dict(textureThreshold=-1), dict(uniquenessRatio=-1)):
+        p = B.make_params(**bad)
+        assert L.rtdm_bm_create(C.byref(p), 64, 48, 1, 0, C.byref(h)) == -1, bad
+    assert L.rtdm_bm_create(None, 64, 48, 1, 0, C.byref(h)) == -7
+    p = B.make_params()
+    assert L.rtdm_bm_create(C.byref(p), 0, 48, 1, 0, C.byref(h)) == -2
+
+
+def test_no_device_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    pkg = load()
+    with pytest.raises(pkg.binding.RtdmError) as e:
+        pkg.HIPMatcher(width=64, height=48)
+    assert e.value.status == -3
+    with pytest.raises(pkg.binding.RtdmError):
+        pkg.HIPMorphologicalFilter(64, 48)
+
+
+def test_product_package_never_touches_the_oracle():
+    pkgdir = os.path.join(ROOT, "rt-depth-map_amd")
+    for dp, _, fs in os.walk(pkgdir):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dp, f), errors="ignore").read()
+                assert "rtdm_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f

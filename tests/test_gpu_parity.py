@@ -1,0 +1,224 @@
+"""GPU parity suite (-m gpu): every case goes through the C ABI (rtdm_bm_* / rtdm_morph_*) and is
+compared BIT-FOR-BIT with the CPU oracle on the same seeded inputs, with the committed golden
+vectors, and -- at BASELINE sizes -- through size-independent properties.  Integer path: the bar is
+exact equality, no tolerance anywhere.  (The oracle itself is parity-unpinned against the real
+OpenCV-backed SWMatcherKonolige, see oracle/rtdm_oracle.h.)"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from conftest import load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu suite needs an MI355X"
+    return load()
+
+
+def run_hip(pkg, L, R, roi1=None, roi2=None, **kw):
+    H, W = L.shape
+    m = pkg.HIPMatcher(numOfDisparities=kw.pop("numDisparities"), width=W, height=H, **kw)
+    if roi1: m.setROI1(roi1)
+    if roi2: m.setROI2(roi2)
+    out = m.compute(L, R)
+    m.close()
+    return out
+
+
+def both(pkg, oracle, L, R, **kw):
+    want = oracle.bm_compute(L, R, **kw)
+    got = run_hip(pkg, L, R, **kw)
+    return got, want
+
+
+def assert_same(got, want):
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("%d / %d pixels differ; first at (y,x)=%s got %d want %d" % (
+            len(bad), got.size, tuple(bad[0]), got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+# ---- golden vectors --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", gu.bm_cases())
+def test_hip_reproduces_bm_golden(pkg, name):
+    L, R, disp, kw = gu.load_bm(name)
+    assert_same(run_hip(pkg, L, R, **kw), disp)
+
+
+@pytest.mark.parametrize("name", gu.morph_cases())
+def test_hip_reproduces_morph_golden(pkg, name):
+    z = gu.load_morph(name)
+    H, W = z["mask"].shape
+    mf = pkg.HIPMorphologicalFilter(W, H, 8)
+    assert np.array_equal(mf.run(z["mask"]), z["mask_out"])
+    assert np.array_equal(mf.run(z["gray"]), z["gray_out"])
+
+
+# ---- staged parity: A.3 alone, + A.4, + A.5 --------------------------------------------------
+CASES = [
+    (64, 48, 16, 5, 0), (96, 64, 32, 7, 0), (97, 65, 16, 9, 0), (80, 50, 16, 13, 0), (131, 77, 48, 11, 0),
+    (96, 64, 16, 7, 4), (96, 64, 16, 7, -5), (90, 40, 32, 5, -40), (200, 90, 96, 9, 0), (72, 60, 16, 21, 0),
+    (300, 70, 128, 7, 0), (90, 80, 16, 33, 0),
+]
+
+
+@pytest.mark.parametrize("W,H,D,w,minD", CASES)
+def test_search_only(pkg, oracle, synth, W, H, D, w, minD):
+    L, R = synth.make_pair(synth.STREAM_SEED + W + H, W, H, D)
+    assert_same(*both(pkg, oracle, L, R, numDisparities=D, blockSize=w, minDisparity=minD,
+                      disp12MaxDiff=-1, speckleWindowSize=0))
+
+
+@pytest.mark.parametrize("W,H,D,w,minD", CASES)
+def test_search_plus_lrcheck(pkg, oracle, synth, W, H, D, w, minD):
+    L, R = synth.make_pair(synth.STREAM_SEED + W + H + 7, W, H, D)
+    for md in (0, 1):
+        assert_same(*both(pkg, oracle, L, R, numDisparities=D, blockSize=w, minDisparity=minD,
+                          disp12MaxDiff=md, speckleWindowSize=0))
+
+
+@pytest.mark.parametrize("W,H,D,w,minD", CASES)
+def test_full_pipeline(pkg, oracle, synth, W, H, D, w, minD):
+    L, R = synth.make_pair(synth.STREAM_SEED + W + H + 13, W, H, D)
+    assert_same(*both(pkg, oracle, L, R, numDisparities=D, blockSize=w, minDisparity=minD,
+                      speckleWindowSize=25, speckleRange=32))
+
+
+@pytest.mark.parametrize("uniq,tex,cap", [(0, 0, 31), (0, 50, 31), (15, 10, 63), (40, 0, 1), (300, 10, 15)])
+def test_rejection_thresholds(pkg, oracle, synth, uniq, tex, cap):
+    L, R = synth.make_pair(synth.STREAM_SEED + 99, 96, 64, 16)
+    assert_same(*both(pkg, oracle, L, R, numDisparities=16, blockSize=7, uniquenessRatio=uniq,
+                      textureThreshold=tex, preFilterCap=cap, speckleWindowSize=0, disp12MaxDiff=-1))
+
+
+# ---- BASELINE configs ------------------------------------------------------------------------
+def test_config1_320x240_d32_w7_and_roi_crop(pkg, oracle, synth):
+    # backup/320x240/extrinsics.yml:56-57 + main.cpp:80-85 -> the 233x156 crop at (49,46), pitch 320
+    L, R = synth.make_pair(synth.STREAM_SEED, 320, 240, 32)
+    assert_same(*both(pkg, oracle, L, R, numDisparities=32, blockSize=7))
+    lv, rv = L[46:46 + 156, 49:49 + 233], R[46:46 + 156, 49:49 + 233]
+    assert not lv.flags["C_CONTIGUOUS"]
+    assert_same(*both(pkg, oracle, lv, rv, numDisparities=32, blockSize=7))
+    # estimator.cpp:54: setROI1(matching_roi) before every compute; ROI2 stays unset
+    roi = (60, 40, 120, 80)
+    assert_same(*both(pkg, oracle, lv, rv, numDisparities=32, blockSize=7, roi1=roi))
+
+
+def test_config2_640x480_d64_w9(pkg, oracle, synth):
+    L, R = synth.make_pair(synth.STREAM_SEED + 1, 640, 480, 64)
+    got, want = both(pkg, oracle, L, R, numDisparities=64, blockSize=9)
+    assert_same(got, want)
+    assert (got != -16).mean() > 0.5
+
+
+def test_config3_1280x720_d128_w11_plus_morph(pkg, oracle, synth):
+    L, R = synth.make_pair(synth.STREAM_SEED + 2, 1280, 720, 128)
+    assert_same(*both(pkg, oracle, L, R, numDisparities=128, blockSize=11))
+    mask = ((L > 120) * 255).astype(np.uint8)
+    mf = pkg.HIPMorphologicalFilter(1280, 720, 8)
+    assert np.array_equal(mf.run(mask), oracle.morph_open_close(mask))
+
+
+def test_reference_default_1280x720_d192_w13(pkg, oracle, synth):
+    # the reference's own flags: nd=192 (cmdline-parser.cpp:22), blockSize 13 (main.cpp:134)
+    L, R = synth.make_pair(synth.STREAM_SEED + 3, 1280, 720, 192)
+    assert_same(*both(pkg, oracle, L, R, numDisparities=192, blockSize=13))
+
+
+def test_headline_1280x720_d64_w9_batch_device(pkg, oracle, synth):
+    import torch
+    n, W, H, D = 6, 1280, 720, 64
+    L, R = synth.make_stream(10, n, W, H, D)
+    dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=9, width=W, height=H, max_batch=4)   # forces 2 chunks
+    m.compute_device(dL, dR, dD, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dD.cpu().numpy()
+    for i in (0, 3, 5):
+        assert_same(got[i], oracle.bm_compute(L[i], R[i], numDisparities=D, blockSize=9, nthreads=8))
+    # batch-position independence: frame 5 alone and in a permuted batch
+    perm = [5, 0, 1, 2, 3, 4]
+    dD2 = torch.empty_like(dD)
+    m.compute_device(dL[perm].contiguous(), dR[perm].contiguous(), dD2, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(dD2[0], dD[5]) and torch.equal(dD2[1], dD[0])
+    # host batch entry point gives the same bytes
+    assert np.array_equal(m.compute_batch(L, R), got)
+
+
+# ---- known-answer properties on the device ---------------------------------------------------
+def test_kat_constant_image_is_all_filtered(pkg):
+    img = np.full((48, 64), 77, np.uint8)
+    assert (run_hip(pkg, img, img, numDisparities=16, blockSize=5) == -16).all()
+
+
+def test_kat_ties_resolve_to_largest_disparity(pkg, oracle):
+    H, W, D = 40, 96, 16
+    row = (np.array([10, 200, 90, 30])[np.arange(W) % 4]).astype(np.uint8)
+    img = (np.tile(row, (H, 1)) + (np.arange(H)[:, None] % 3) * 7).astype(np.uint8)
+    kw = dict(numDisparities=D, blockSize=5, uniquenessRatio=0, textureThreshold=0, speckleWindowSize=0, disp12MaxDiff=-1)
+    got, want = both(pkg, oracle, img, img, **kw)
+    assert_same(got, want)
+    assert (((got[2:-2, D + 1:W - 3] + 8) >> 4) == 12).all()
+
+
+def test_kat_too_narrow_image_is_all_filtered(pkg):
+    img = np.random.default_rng(0).integers(0, 255, (40, 30), dtype=np.uint8)
+    assert (run_hip(pkg, img, img, numDisparities=32, blockSize=5) == -16).all()
+
+
+def test_kat_speckle_boundary_through_pipeline(pkg, oracle, synth):
+    L, R = synth.make_pair(synth.STREAM_SEED + 21, 200, 120, 32)
+    for win in (99, 100, 400):
+        assert_same(*both(pkg, oracle, L, R, numDisparities=32, blockSize=9, speckleWindowSize=win))
+
+
+def test_error_behaviour_matches_header(pkg, synth):
+    L, R = synth.make_pair(synth.STREAM_SEED, 64, 48, 16)
+    m = pkg.HIPMatcher(numOfDisparities=16, blockSize=5, width=64, height=48)
+    big = np.zeros((60, 80), np.uint8)
+    with pytest.raises(pkg.binding.RtdmError) as e:
+        m.compute(big, big)
+    assert e.value.status == -2
+    m2 = pkg.HIPMatcher(numOfDisparities=16, blockSize=49, width=64, height=48)   # >= min(W,H): cv::StereoBM rejects at compute
+    with pytest.raises(pkg.binding.RtdmError) as e:
+        m2.compute(L, R)
+    assert e.value.status == -1
+
+
+# ---- morphology ------------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H", [(64, 48), (37, 29), (12, 9), (233, 156), (640, 480)])
+def test_morph_matches_oracle(pkg, oracle, W, H):
+    rng = np.random.default_rng(W * H)
+    mf = pkg.HIPMorphologicalFilter(W, H, 8)
+    mask = ((rng.random((H, W)) < 0.5) * 255).astype(np.uint8)
+    gray = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    assert np.array_equal(mf.run(mask), oracle.morph_open_close(mask))
+    assert np.array_equal(mf.run(gray), oracle.morph_open_close(gray))
+
+
+def test_morph_video_buffers_round_trip(pkg, oracle):
+    # estimator.cpp:141-142 wraps getVideoInBuffer()/getVideoOutBuffer() as Mats once and reuses them
+    W, H = 233, 156
+    mf = pkg.HIPMorphologicalFilter(W, H, 8)
+    vin, vout = mf.getVideoInBuffer(), mf.getVideoOutBuffer()
+    assert vin.shape == (H, W) and mf.getFrameSize() == W * H
+    vin[:] = ((np.random.default_rng(3).random((H, W)) < 0.6) * 255).astype(np.uint8)
+    mf.run(vin, vout)
+    assert np.array_equal(vout, oracle.morph_open_close(vin))
+
+
+# ---- synthetic stream ------------------------------------------------------------------------
+@pytest.mark.parametrize("W,H,D", [(96, 64, 16), (320, 240, 32), (1280, 720, 64)])
+def test_device_synth_is_bit_identical_to_numpy(pkg, synth, W, H, D):
+    import torch
+    n = 3
+    dL = torch.empty((n, H, W), dtype=torch.uint8, device="cuda"); dR = torch.empty_like(dL)
+    pkg.synth_pairs_device(dL, dR, first_frame=5, numDisparities=D)
+    L, R = synth.make_stream(5, n, W, H, D)
+    assert np.array_equal(dL.cpu().numpy(), L) and np.array_equal(dR.cpu().numpy(), R)
