@@ -136,19 +136,36 @@ void launch_lrcheck(Plane16W disp, const int32_t* cost, const BMGeom& g, int dis
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4 speckle filter: union-find over the pixel graph (4-neighbour edges with |a-b| <= maxDiff
-// between pixels != newVal).  Parent pointers only ever decrease, all updates are device-scope
-// atomicMin, so stale reads are still ancestors and the result (which components are small) is
-// independent of scheduling.  Components never span frames.
+// K4 speckle filter (cv::filterSpeckles as called by cv::StereoBM::compute, SURVEY.md Appendix
+// A.5): 4-connected components of pixels != newVal under |a-b| <= maxDiff; components with
+// size <= maxSize become newVal.  Run-based union-find:
+//   init   one workgroup per row: a max-scan turns the "connected to my left neighbour" flags into
+//          run heads; every pixel of a horizontal run is represented by its head, which starts as
+//          its own parent and carries the run length.
+//   merge  one workgroup per row pair: ONE union per vertical contact segment between two runs
+//          (a pixel is skipped when its left neighbour already linked the same two runs).
+//   count  every non-root head adds its run length to its root (skipped once the root is known to
+//          be large: only "<= maxSize" matters) and is re-pointed straight at the root.
+//   apply  one workgroup per row: heads chase to their root, look its size up once, pixels read the flag.
+// Parent pointers only ever move to smaller indices of the same component and every hook is a
+// device-scope atomicMin on a root, so stale reads are still ancestors and the set of small
+// components is independent of scheduling.  Components never span frames.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int uf_find(const int32_t* parent, int x)
+__device__ __forceinline__ int ld_relaxed(const int32_t* p)
+{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_relaxed(int32_t* p, int v)
+{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int uf_find(int32_t* parent, int x)   // with path halving
 {
-    int p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (p != x) {
-        x = p;
-        p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        const int p = ld_relaxed(&parent[x]);
+        if (p == x) return x;
+        const int gp = ld_relaxed(&parent[p]);
+        if (gp == p) return p;
+        st_relaxed(&parent[x], gp);
+        x = gp;
     }
-    return x;
 }
 
 __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b)
@@ -157,75 +174,161 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b)
         a = uf_find(parent, a);
         b = uf_find(parent, b);
         if (a == b) return;
-        if (a < b) { int t = a; a = b; b = t; }   // a > b: hang a under b
+        if (a < b) { const int t = a; a = b; b = t; }   // a > b: hang a under b
         const int old = atomicMin(&parent[a], b);
         if (old == a) return;
-        a = old;                                   // a was no longer a root; retry from its parent
+        a = old;                                         // a was no longer a root; retry from its parent
     }
 }
 
-__global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label, int32_t* size, int W, int H, int newVal)
+// Inclusive max-scan over hp[0..W) (LDS, int16: x at run heads, -1 elsewhere), 256 threads,
+// contiguous chunks per thread.  Must be called by the whole workgroup; ends with a barrier.
+__device__ __forceinline__ void head_scan(int16_t* hp, int W, int* wsum)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int CH = (W + 255) >> 8;
+    const int x0 = tid * CH;
+    int run = -1;
+    for (int k = 0; k < CH; ++k) {
+        const int x = x0 + k;
+        if (x < W) { run = max(run, (int)hp[x]); hp[x] = (int16_t)run; }
+    }
+    int v = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(v, o);
+        if (lane >= o) v = max(v, u);
+    }
+    if (lane == 63) wsum[wv] = v;
+    __syncthreads();
+    int excl = __shfl_up(v, 1);
+    if (lane == 0) excl = -1;
+    for (int q = 0; q < wv; ++q) excl = max(excl, wsum[q]);
+    for (int k = 0; k < CH; ++k) {
+        const int x = x0 + k;
+        if (x < W) hp[x] = (int16_t)max((int)hp[x], excl);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool conn(int a, int b, int newVal, int maxDiff)
+{ return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
+
+__global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label, int32_t* size, int W, int H,
+                                                  int newVal, int maxDiff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int16_t* d = (int16_t*)smem;          // W
+    int16_t* hp = d + W;                  // W
+    __shared__ int wsum[4];
     const int y = blockIdx.y, f = blockIdx.z;
-    const int idx = (f * H + y) * W + x;
-    const int d = disp.base[(size_t)f * disp.frame_e + (size_t)y * disp.pitch_e + x];
-    label[idx] = (d != newVal) ? idx : -1;
-    size[idx] = 0;
+    const int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    const int base = (f * H + y) * W;
+    for (int x = threadIdx.x; x < W; x += 256) d[x] = row[x];
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int v = d[x];
+        const bool head = v != newVal && !(x > 0 && conn(v, d[x - 1], newVal, maxDiff));
+        hp[x] = head ? (int16_t)x : (int16_t)-1;
+    }
+    __syncthreads();
+    head_scan(hp, W, wsum);
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int v = d[x];
+        if (v == newVal) continue;
+        const int h = hp[x];
+        if (h == x) label[base + x] = base + x;
+        const bool last = (x == W - 1) || !conn(v, d[x + 1], newVal, maxDiff);
+        if (last) size[base + h] = x - h + 1;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, int W, int H, int newVal, int maxDiff)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    const int y = blockIdx.y, f = blockIdx.z;
-    const int16_t* base = disp.base + (size_t)f * disp.frame_e;
-    const int d = base[(size_t)y * disp.pitch_e + x];
-    if (d == newVal) return;
-    const int idx = (f * H + y) * W + x;
-    if (x + 1 < W) {
-        const int e = base[(size_t)y * disp.pitch_e + x + 1];
-        if (e != newVal && abs(d - e) <= maxDiff) uf_union(label, idx, idx + 1);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int16_t* d0 = (int16_t*)smem;
+    int16_t* d1 = d0 + W;
+    int16_t* h0 = d1 + W;
+    int16_t* h1 = h0 + W;
+    __shared__ int wsum[4];
+    const int y = blockIdx.y, f = blockIdx.z;      // rows y and y+1
+    const int16_t* r0 = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    const int16_t* r1 = r0 + disp.pitch_e;
+    const int base0 = (f * H + y) * W, base1 = base0 + W;
+    for (int x = threadIdx.x; x < W; x += 256) { d0[x] = r0[x]; d1[x] = r1[x]; }
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int a = d0[x], b = d1[x];
+        h0[x] = (a != newVal && !(x > 0 && conn(a, d0[x - 1], newVal, maxDiff))) ? (int16_t)x : (int16_t)-1;
+        h1[x] = (b != newVal && !(x > 0 && conn(b, d1[x - 1], newVal, maxDiff))) ? (int16_t)x : (int16_t)-1;
     }
-    if (y + 1 < H) {
-        const int e = base[(size_t)(y + 1) * disp.pitch_e + x];
-        if (e != newVal && abs(d - e) <= maxDiff) uf_union(label, idx, idx + W);
+    __syncthreads();
+    head_scan(h0, W, wsum);
+    head_scan(h1, W, wsum);
+    for (int x = threadIdx.x; x < W; x += 256) {
+        if (!conn(d0[x], d1[x], newVal, maxDiff)) continue;
+        const bool dup = x > 0 && conn(d0[x - 1], d1[x - 1], newVal, maxDiff) && h0[x - 1] == h0[x] && h1[x - 1] == h1[x];
+        if (!dup) uf_union(label, base0 + h0[x], base1 + h1[x]);
     }
 }
 
-__global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, int total)
+__global__ __launch_bounds__(256) void k_spk_count(Plane16W disp, int32_t* label, int32_t* size, int W, int H,
+                                                   int newVal, int maxDiff, int maxSize)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    if (label[idx] < 0) return;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int y = blockIdx.y, f = blockIdx.z;
+    const int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    const int v = row[x];
+    if (v == newVal) return;
+    if (x > 0 && conn(v, row[x - 1], newVal, maxDiff)) return;      // not a run head
+    const int idx = (f * H + y) * W + x;
     const int root = uf_find(label, idx);
-    label[idx] = root;            // roots are final here (no unions in this launch)
-    atomicAdd(&size[root], 1);
+    if (root == idx) return;
+    st_relaxed(&label[idx], root);             // roots are final in this launch
+    if (ld_relaxed(&size[root]) <= maxSize) atomicAdd(&size[root], size[idx]);
 }
 
 __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t* label, const int32_t* size,
-                                                   int W, int H, int newVal, int maxSize)
+                                                   int W, int H, int newVal, int maxDiff, int maxSize)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int16_t* d = (int16_t*)smem;          // W
+    int16_t* hp = d + W;                  // W
+    uint8_t* small = (uint8_t*)(hp + W);  // W
+    __shared__ int wsum[4];
     const int y = blockIdx.y, f = blockIdx.z;
-    const int idx = (f * H + y) * W + x;
-    const int root = label[idx];
-    if (root < 0) return;
-    if (size[root] <= maxSize)
-        disp.base[(size_t)f * disp.frame_e + (size_t)y * disp.pitch_e + x] = (int16_t)newVal;
+    int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    const int base = (f * H + y) * W;
+    for (int x = threadIdx.x; x < W; x += 256) d[x] = row[x];
+    __syncthreads();
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int v = d[x];
+        const bool head = v != newVal && !(x > 0 && conn(v, d[x - 1], newVal, maxDiff));
+        hp[x] = head ? (int16_t)x : (int16_t)-1;
+        if (head) {
+            // after k_spk_count a head is at most a couple of hops from its root (a late path-halving
+            // store of another thread may have left an ancestor instead of the root), so chase it
+            int root = base + x;
+            for (int p = label[root]; p != root; p = label[root]) root = p;
+            small[x] = size[root] <= maxSize;
+        }
+    }
+    __syncthreads();
+    head_scan(hp, W, wsum);
+    for (int x = threadIdx.x; x < W; x += 256)
+        if (d[x] != newVal && small[hp[x]]) row[x] = (int16_t)newVal;
 }
 
 void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, int W, int H, int n, int newVal,
                     int maxSize, int maxDiff, hipStream_t stream)
 {
-    dim3 grid((W + 255) / 256, H, n), block(256);
-    const int total = n * W * H;
-    hipLaunchKernelGGL(k_spk_init, grid, block, 0, stream, disp, label, size, W, H, newVal);
-    hipLaunchKernelGGL(k_spk_merge, grid, block, 0, stream, disp, label, W, H, newVal, maxDiff);
-    hipLaunchKernelGGL(k_spk_count, dim3((total + 255) / 256), block, 0, stream, label, size, total);
-    hipLaunchKernelGGL(k_spk_apply, grid, block, 0, stream, disp, label, size, W, H, newVal, maxSize);
+    dim3 rows(1, H, n), block(256);
+    hipLaunchKernelGGL(k_spk_init, rows, block, (size_t)W * 4, stream, disp, label, size, W, H, newVal, maxDiff);
+    if (H > 1)
+        hipLaunchKernelGGL(k_spk_merge, dim3(1, H - 1, n), block, (size_t)W * 8, stream, disp, label, W, H, newVal, maxDiff);
+    hipLaunchKernelGGL(k_spk_count, dim3((W + 255) / 256, H, n), block, 0, stream, disp, label, size, W, H, newVal, maxDiff, maxSize);
+    hipLaunchKernelGGL(k_spk_apply, rows, block, (size_t)W * 5, stream, disp, label, size, W, H, newVal, maxDiff, maxSize);
 }
 
 }  // namespace rtdm

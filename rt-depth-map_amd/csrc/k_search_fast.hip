@@ -1,8 +1,345 @@
-// k_search_fast.hip -- K2, fast variant (packed-u8 quad-SAD).  Placeholder until the kernel lands:
-// every configuration is routed to the generic variant.
+// k_search_fast.hip -- K2, fast variant: the SAD window search as packed-u8 quad-SAD on CDNA4.
+//
+// Mapping (one workgroup = 256 output columns x `rs` output rows of one frame, 4 waves):
+//   * wave = phase phi in 0..3, lane l handles output column x = x_tile + phi + 4*l.  All lanes of
+//     a wave therefore share one byte alignment, so each wave reads its own byte-shifted copy of
+//     the staged rows with plain aligned dword LDS reads (consecutive lanes -> consecutive banks).
+//   * per lane, ALL D reversed-disparity SADs live in registers as packed u16 (D/2 VGPRs).
+//   * horizontal: one v_qsad_pk_u16_u8 gives 4 consecutive disparities x 4 window bytes; the
+//     window row is ceil(w/4) pieces, the last one masked (v_mqsad_pk_u16_u8 skips zero reference
+//     bytes, so staged bytes carry a +1 bias and masked bytes are 0).
+//   * vertical: sliding window down the strip.  The entering row accumulates straight into the
+//     running sums (the quad-SAD's accumulator operand); the leaving row is recomputed from the
+//     LDS ring and subtracted with v_pk_sub_u16.
+//   * selection per output pixel, all in registers: 32-bit keys (sad << 8 | e) built by v_perm and
+//     reduced with v_min3_u32 give (minsad, FIRST argmin); uniqueness is the identity
+//       sum_e max(T+1 - sad[e], 0)  ==  the same sum over {mind-1, mind, mind+1}
+//     evaluated with saturating packed u16 ops; sad[mind +- 1] come out of a 5-level v_cndmask tree.
+//   Only columns whose whole window is free of border clamping are handled here; the 2*(w/2)
+//   border columns go to the generic kernel (they are outside the valid rectangle but feed the
+//   left-right check).  Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
 #include "rtdm_kernels.h"
 
 namespace rtdm {
-bool fast_search_supported(const BMGeom&) { return false; }
-void launch_search_fast(Plane8, Plane8, Plane16W, int32_t*, const BMGeom&, int, hipStream_t) {}
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
+
+struct FastGeom {
+    int x0, nx;          // output-column range [x0, x0+nx) handled by this kernel
+    int rs;              // output rows per workgroup
+    uint32_t lastmask;   // byte mask of the last (partial) window piece
+};
+
+template <int D, int NP>
+struct FastCfg {
+    static constexpr int NG = D / 4;            // quad-SAD groups (4 disparities each)
+    static constexpr int NW = NG + NP - 1;      // distinct 8-byte right windows per row visit
+    static constexpr int NR = D / 2;            // packed u16x2 registers holding sad[0..D)
+    static constexpr int LWD = 64 + NP;         // dwords per byte-shifted copy of the left row
+    static constexpr int RWD = 64 + NG + NP;    // dwords per byte-shifted copy of the right row
+    static constexpr int SLOT = 4 * (LWD + RWD);
+    static constexpr int ITEMS = (SLOT + 255) / 256;
+};
+
+// Horizontal SADs of one staged row for this lane's column: acc[g] += the 4 packed SADs of
+// disparity group g; tacc += sum |L - cap| over the window row.
+template <int D, int NP>
+__device__ __forceinline__ void row_sads(const uint32_t* __restrict__ lp, const uint32_t* __restrict__ rp,
+                                         uint32_t lastmask, uint32_t capb, uint64_t (&acc)[D / 4], uint32_t& tacc)
+{
+    using C = FastCfg<D, NP>;
+    uint32_t l[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) l[k] = lp[k];
+    l[NP - 1] &= lastmask;
+#pragma unroll
+    for (int k = 0; k < NP - 1; ++k) tacc = __builtin_amdgcn_sad_u8(l[k], capb, tacc);
+    tacc = __builtin_amdgcn_msad_u8(capb, l[NP - 1], tacc);   // zero bytes of the reference are skipped
+    // gfx950 wants 64-bit operands in even-aligned VGPR pairs.  Windows at odd dword offsets are
+    // loaded through a second, laundered pointer so that the compiler issues its own ds_read2_b32
+    // for them instead of rebuilding the pair from already-loaded dwords with v_mov.
+    // (the laundered value is the INDEX, so the pointer keeps its LDS address space)
+    int one = 1;
+    asm volatile("" : "+v"(one));
+    const uint32_t* rpo = rp + one;
+#pragma unroll
+    for (int j = 0; j < C::NW; ++j) {
+        const uint32_t* wp = (j & 1) ? rpo + (j - 1) : rp + j;
+        const uint64_t win = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int gi = j - k;
+            if (gi >= 0 && gi < C::NG) {
+                if (k == NP - 1) acc[gi] = __builtin_amdgcn_mqsad_pk_u16_u8(win, l[k], acc[gi]);
+                else             acc[gi] = __builtin_amdgcn_qsad_pk_u16_u8(win, l[k], acc[gi]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ int div_trunc_small(int num, int den)   // den > 0, |num| < 2^24
+{
+    const unsigned an = (unsigned)(num < 0 ? -num : num);
+    unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
+    int rem = (int)an - (int)(q * (unsigned)den);
+    if (rem < 0) { --q; rem += den; }
+    if (rem < 0) { --q; rem += den; }
+    if (rem >= den) { ++q; rem -= den; }
+    if (rem >= den) { ++q; }
+    return num < 0 ? -(int)q : (int)q;
+}
+
+template <int D, int NP>
+__global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost,
+                                                     BMGeom g, FastGeom fg)
+{
+    using C = FastCfg<D, NP>;
+    constexpr int NG = C::NG, NR = C::NR, LWD = C::LWD, RWD = C::RWD, SLOT = C::SLOT, ITEMS = C::ITEMS;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int phi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x_tile = fg.x0 + blockIdx.x * 256;
+    const int x = x_tile + phi + 4 * lane;
+    const bool active = x < fg.x0 + fg.nx;
+    const int ys0 = g.vy0 + blockIdx.y * fg.rs;
+    const int ys1 = min(ys0 + fg.rs, g.vy1);
+    const int f = blockIdx.z;
+    const int w = g.w, r = g.r, RING = g.w + 2;
+    const uint8_t* Lb = Lp.base + (size_t)f * Lp.frame;
+    const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
+    const int Lbase = g.lofs + x_tile - r;   // image column of tile-row byte 0 (left)
+    const int Rbase = g.rofs + x_tile - r;   //                                  (right)
+    const uint32_t capb = (uint32_t)(g.cap + 1) * 0x01010101u;
+
+    // --- staging: every item = one dword of one byte-shifted copy ------------------------------
+    // item idx in [0, 4*LWD): left copy c = idx / LWD, dword m = idx % LWD; then the right copies.
+    // copy c, dword m holds tile-row bytes [c + 4m, c + 4m + 4), biased by +1.
+    int it_q[ITEMS], it_sh[ITEMS];
+    bool it_r[ITEMS], it_ok[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = tid + it * 256;
+        const bool isr = idx >= 4 * LWD;
+        const int ii = isr ? idx - 4 * LWD : idx;
+        const int c = isr ? ii / RWD : ii / LWD;
+        const int m = isr ? ii - c * RWD : ii - c * LWD;
+        const int col = (isr ? Rbase : Lbase) + c + 4 * m;
+        it_r[it] = isr; it_q[it] = col & ~3; it_sh[it] = col & 3; it_ok[it] = idx < SLOT;
+    }
+    const int pitch_lim = (int)Lp.pitch;     // both prefiltered planes share pitch and allocation slack
+    uint32_t pre[ITEMS][2];
+    auto issue = [&](int row) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint8_t* rowp = (it_r[it] ? Rb : Lb) + (size_t)row * Lp.pitch;
+            const int q = it_q[it];
+            pre[it][0] = (it_ok[it] && q + 4 <= pitch_lim) ? *(const uint32_t*)(rowp + q) : 0u;
+            pre[it][1] = (it_ok[it] && q + 8 <= pitch_lim) ? *(const uint32_t*)(rowp + q + 4) : 0u;
+        }
+    };
+    auto commit = [&](int slot) {
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t v = __builtin_amdgcn_alignbyte(pre[it][1], pre[it][0], (uint32_t)it_sh[it]);
+            if (it_ok[it]) lds[slot * SLOT + tid + it * 256] = v + 0x01010101u;
+        }
+    };
+
+    uint64_t S[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) S[i] = 0;
+    uint32_t tsum = 0;
+
+    issue(ys0 - r);
+    commit(0);
+    __syncthreads();
+
+    const int nsteps = (ys1 - ys0) + w - 1;
+    int slot_in = 0, slot_out = 0, slot_next = 1;   // slot_out trails slot_in by w steps
+    int16_t* db = disp.base + (size_t)f * disp.frame_e;
+    const int col = g.lofs + x;
+    const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
+
+    for (int s = 0; s < nsteps; ++s) {
+        const int row_in = ys0 - r + s;
+        const bool more = s + 1 < nsteps;
+        if (more) issue(row_in + 1);
+
+        {   // entering row: accumulate straight into the running sums
+            const uint32_t* lp = lds + slot_in * SLOT + phi * LWD + lane;
+            const uint32_t* rp = lds + slot_in * SLOT + 4 * LWD + phi * RWD + lane;
+            row_sads<D, NP>(lp, rp, fg.lastmask, capb, S, tsum);
+        }
+        if (s >= w) {   // leaving row: recompute and subtract
+            const uint32_t* lp = lds + slot_out * SLOT + phi * LWD + lane;
+            const uint32_t* rp = lds + slot_out * SLOT + 4 * LWD + phi * RWD + lane;
+            uint64_t T[NG];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) T[i] = 0;
+            uint32_t told = 0;
+            row_sads<D, NP>(lp, rp, fg.lastmask, capb, T, told);
+#pragma unroll
+            for (int i = 0; i < NG; ++i) {
+                const uint32_t lo = pk_sub((uint32_t)S[i], (uint32_t)T[i]);
+                const uint32_t hi = pk_sub((uint32_t)(S[i] >> 32), (uint32_t)(T[i] >> 32));
+                S[i] = (uint64_t)lo | ((uint64_t)hi << 32);
+            }
+            tsum -= told;
+            slot_out = (slot_out + 1 == RING) ? 0 : slot_out + 1;
+        }
+
+        if (s >= w - 1) {
+            const int y = row_in - r;
+            uint32_t rr[NR];
+#pragma unroll
+            for (int i = 0; i < NG; ++i) { rr[2 * i] = (uint32_t)S[i]; rr[2 * i + 1] = (uint32_t)(S[i] >> 32); }
+            // (minsad, first argmin) via 32-bit keys sad << 8 | e
+            uint32_t kmin = 0xffffffffu;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const uint32_t ec = (uint32_t)(2 * i) | ((uint32_t)(2 * i + 1) << 8);
+                const uint32_t klo = __builtin_amdgcn_perm(rr[i], ec, 0x0C050400u);
+                const uint32_t khi = __builtin_amdgcn_perm(rr[i], ec, 0x0C070601u);
+                kmin = min(min(kmin, klo), khi);
+            }
+            const int m1 = (int)(kmin >> 8);
+            const int a = (int)(kmin & 0xffu);
+            // fetch the two packed registers that hold sad[a-1 .. a+1]
+            const int am1 = a > 0 ? a - 1 : 0;
+            const int j = am1 >> 1;
+            uint32_t cur[NR + 1];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) cur[i] = rr[i];
+            cur[NR] = 0;
+            {
+                constexpr int HB = (NR - 1) >= 64 ? 64 : (NR - 1) >= 32 ? 32 : (NR - 1) >= 16 ? 16 : (NR - 1) >= 8 ? 8 : 4;
+                int len = NR + 1;
+#pragma unroll
+                for (int bit = HB; bit >= 1; bit >>= 1) {
+                    const bool up = (j & bit) != 0;
+#pragma unroll
+                    for (int i = 0; i < bit + 1; ++i) {
+                        if (i < len) {
+                            const uint32_t hi = (i + bit < len) ? cur[i + bit] : 0u;
+                            cur[i] = up ? hi : cur[i];
+                        }
+                    }
+                    len = (bit + 1 < len) ? bit + 1 : len;
+                }
+            }
+            const uint32_t e0 = cur[0], e1 = cur[1];
+            const int posc = a > 0 ? (am1 & 1) + 1 : 0;         // position of sad[a] among the 4 fetched
+            const auto elem = [&](int pos) -> int {
+                return (int)__builtin_amdgcn_perm(e1, e0, 0x0C0C0100u + 0x0202u * (uint32_t)pos);
+            };
+            const bool has_n = a > 0, has_p = a + 1 < D;
+            const int n_real = elem(has_n ? posc - 1 : 0);
+            const int p_real = elem(has_p ? posc + 1 : 0);
+            bool fail = (int)tsum < g.tex;
+            if (g.uniq > 0) {
+                uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
+                T = min(T, 32766u);
+                const uint32_t T1 = T + 1u, T1pk = T1 * 0x00010001u;
+                uint32_t z = 0;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) z = pk_add_sat(z, pk_sub_sat(T1pk, rr[i]));
+                const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
+                const uint32_t wsame = term(m1);
+                const uint32_t wother = (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
+                const uint32_t zlo = z & 0xffffu, zhi = z >> 16;
+                const bool even = (a & 1) == 0;
+                fail |= (even ? zlo : zhi) != wsame;
+                fail |= (even ? zhi : zlo) != wother;
+            }
+            int out = g.filtered;
+            if (!fail) {
+                const int pp = has_p ? p_real : n_real;
+                const int nn = has_n ? n_real : p_real;
+                const int den = pp + nn - 2 * m1 + abs(pp - nn);
+                const int q = den != 0 ? div_trunc_small((pp - nn) * 256, den) : 0;
+                out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
+            }
+            if (active) {
+                if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = m1;
+                db[(size_t)y * disp.pitch_e + col] = (int16_t)(masked_col ? g.filtered : out);
+            }
+        }
+
+        if (more) commit(slot_next);
+        slot_in = slot_next;
+        slot_next = (slot_next + 1 == RING) ? 0 : slot_next + 1;
+        __syncthreads();
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------
+static bool fast_range(const BMGeom& g, int* x0, int* nx)
+{
+    const int r = g.r;
+    int xl = 0, xh = g.width1 - 1;
+    xl = max(xl, r - g.lofs); xl = max(xl, r - g.rofs);
+    xh = min(xh, g.W - 1 - g.lofs - r); xh = min(xh, g.W - g.D - g.rofs - r);
+    if (x0) *x0 = xl;
+    if (nx) *nx = xh - xl + 1;
+    return xh >= xl;
+}
+
+static int fast_np(const BMGeom& g) { return (g.w + 3) / 4; }
+
+template <int D, int NP>
+static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g, int n, hipStream_t stream)
+{
+    using C = FastCfg<D, NP>;
+    FastGeom fg;
+    fast_range(g, &fg.x0, &fg.nx);
+    const int rem = g.w - 4 * (NP - 1);
+    fg.lastmask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+    const int nrows = g.vy1 - g.vy0;
+    const int tiles = (fg.nx + 255) / 256;
+    int strips = (2048 + tiles * n - 1) / (tiles * n);
+    strips = max(1, min(strips, (nrows + 31) / 32));
+    fg.rs = (nrows + strips - 1) / strips;
+    strips = (nrows + fg.rs - 1) / fg.rs;
+    const size_t ldsb = (size_t)(g.w + 2) * C::SLOT * 4;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_search_fast<D, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, cost, g, fg);
+}
+
+bool fast_search_supported(const BMGeom& g)
+{
+    if (2L * g.cap * g.w * g.w > 32766) return false;       // packed u16 sums + the T+1 <= 32767 argument
+    if (!fast_range(g, nullptr, nullptr)) return false;
+    const int np = fast_np(g);
+    if (g.D == 64 && np == 3) return true;
+    if (g.D == 32 && np == 2) return true;
+    if (g.D == 128 && np == 3) return true;
+    if (g.D == 192 && np == 4) return true;
+    return false;
+}
+
+void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g, int n, hipStream_t stream)
+{
+    const int np = fast_np(g);
+    if (g.D == 64 && np == 3) launch_one<64, 3>(Lp, Rp, disp, cost, g, n, stream);
+    else if (g.D == 32 && np == 2) launch_one<32, 2>(Lp, Rp, disp, cost, g, n, stream);
+    else if (g.D == 128 && np == 3) launch_one<128, 3>(Lp, Rp, disp, cost, g, n, stream);
+    else if (g.D == 192 && np == 4) launch_one<192, 4>(Lp, Rp, disp, cost, g, n, stream);
+}
+
+void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1)
+{
+    int x0 = 0, nx = 0;
+    fast_range(g, &x0, &nx);
+    *lx0 = 0; *lx1 = x0; *rx0 = x0 + nx; *rx1 = g.width1;
+}
+
 }  // namespace rtdm

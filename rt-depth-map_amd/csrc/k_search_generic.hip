@@ -17,11 +17,13 @@
 
 namespace rtdm {
 
-static constexpr int TC = 64;   // output columns per workgroup
 static constexpr int RS = 24;   // output rows per workgroup
 
-template <typename T>
-__global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, BMGeom g)
+// TC = output columns per workgroup: 64 for whole frames, 8 for the narrow border strips that
+// the fast kernel leaves over (work per workgroup scales with TC + w - 1 sample columns).
+template <typename T, int TC>
+__global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, BMGeom g,
+                                                        int gx0, int gx1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int D = g.D, w = g.w, r = g.r;
@@ -32,9 +34,10 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
     T* V = (T*)smem;                                     // D * TCH
     T* Ssc = V + (size_t)D * TCH + ((D * TCH) & 1);      // D * TC
     int* Tcol = (int*)(Ssc + (size_t)D * TC);            // TCH
-    int* pmin = Tcol + TCH;                              // 4 * TC
-    int* pidx = pmin + 4 * TC;                           // 4 * TC
-    int* uflag = pidx + 4 * TC;                          // TC
+    constexpr int NQ = 256 / TC;                         // slices of the disparity range
+    int* pmin = Tcol + TCH;                              // NQ * TC = 256
+    int* pidx = pmin + 256;                              // 256
+    int* uflag = pidx + 256;                             // TC
     int* m1s = uflag + TC;                               // TC
     int* mis = m1s + TC;                                 // TC
     short* lidx = (short*)(mis + TC);                    // TCH (left column of sample j)
@@ -45,7 +48,8 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
     uint8_t* Ro = Rn + RW;
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x_tile = blockIdx.x * TC;                  // first output column index of the tile
+    const int c = tid % TC, qs = tid / TC;               // output column within the tile, disparity slice
+    const int x_tile = gx0 + blockIdx.x * TC;            // first output column index of the tile
     const int ys0 = g.vy0 + blockIdx.y * RS;
     const int ys1 = min(ys0 + RS, g.vy1);
     const int f = blockIdx.z;
@@ -102,12 +106,11 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
         if (s < w - 1) continue;
 
         const int y = row_in - r;
-        const int c = lane;                       // output column within the tile
         const int x = x_tile + c;                 // output column index
         const int col = g.lofs + x;               // image column
-        const bool active = (x < g.width1) && (col < g.W);
+        const bool active = (x < gx1) && (col < g.W);
         // horizontal sums for this wave's slice of the disparity range
-        const int e0 = (D * wv) >> 2, e1 = (D * (wv + 1)) >> 2;
+        const int e0 = (D * qs) / NQ, e1 = (D * (qs + 1)) / NQ;
         int best = 0x7fffffff, besti = -1;
         for (int e = e0; e < e1; ++e) {
             const T* v = V + (size_t)e * TCH + c;
@@ -116,12 +119,12 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
             Ssc[(size_t)e * TC + c] = (T)sum;
             if (sum < best) { best = sum; besti = e; }
         }
-        pmin[wv * TC + c] = best; pidx[wv * TC + c] = besti;
-        if (wv == 0) uflag[c] = 0;
+        pmin[qs * TC + c] = best; pidx[qs * TC + c] = besti;
+        if (qs == 0) uflag[c] = 0;
         __syncthreads();
         int m1 = 0x7fffffff, mi = -1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int b = pmin[q * TC + c];
             if (b < m1) { m1 = b; mi = pidx[q * TC + c]; }
         }
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
             if (hit) atomicOr(&uflag[c], 1);
         }
         __syncthreads();
-        if (wv == 0 && active) {
+        if (qs == 0 && active) {
             int tsum = 0;
             for (int k = 0; k < w; ++k) tsum += Tcol[c + k];
             int out = g.filtered;
@@ -152,13 +155,13 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
     }
 }
 
-static size_t generic_lds_bytes(const BMGeom& g, bool use16)
+static size_t generic_lds_bytes(const BMGeom& g, bool use16, int TC = 64)
 {
     const size_t ts = use16 ? 2 : 4;
     const int TCH = TC + g.w - 1;
     const int RW = (TCH + g.D + 3) & ~3, LW = (TCH + 3) & ~3;
     size_t b = ((size_t)g.D * TCH + ((g.D * TCH) & 1)) * ts + (size_t)g.D * TC * ts;
-    b += (size_t)(TCH + 4 * TC * 2 + 3 * TC) * 4;
+    b += (size_t)(TCH + 2 * 256 + 3 * TC) * 4;
     b += (size_t)2 * (TCH + (TCH & 1)) * 2;
     b += (size_t)2 * LW + 2 * RW;
     return (b + 15) & ~(size_t)15;
@@ -173,21 +176,31 @@ bool generic_search_supported(const BMGeom& g, bool* use16)
     return generic_lds_bytes(g, u16) <= 160 * 1024;
 }
 
-void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g,
-                           int n, hipStream_t stream)
+template <typename T, int TC>
+static void launch_generic_t(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g, int n,
+                             hipStream_t stream, int gx0, int gx1, size_t lds)
 {
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)k_search_generic<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    dim3 grid((gx1 - gx0 + TC - 1) / TC, (g.vy1 - g.vy0 + RS - 1) / RS, n);
+    hipLaunchKernelGGL((k_search_generic<T, TC>), grid, dim3(256), lds, stream, Lp, Rp, disp, cost, g, gx0, gx1);
+}
+
+void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g,
+                           int n, hipStream_t stream, int gx0, int gx1)
+{
+    if (gx1 < 0) gx1 = g.width1;
+    if (gx1 <= gx0) return;
     bool u16 = false;
     generic_search_supported(g, &u16);
-    const size_t lds = generic_lds_bytes(g, u16);
-    dim3 grid((g.width1 + TC - 1) / TC, (g.vy1 - g.vy0 + RS - 1) / RS, n);
+    const bool narrow = (gx1 - gx0) <= 16;
+    const size_t lds = generic_lds_bytes(g, u16, narrow ? 8 : 64);
     if (u16) {
-        static bool attr16 = false;
-        if (!attr16) { (void)hipFuncSetAttribute((const void*)k_search_generic<uint16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr16 = true; }
-        hipLaunchKernelGGL(k_search_generic<uint16_t>, grid, dim3(256), lds, stream, Lp, Rp, disp, cost, g);
+        if (narrow) launch_generic_t<uint16_t, 8>(Lp, Rp, disp, cost, g, n, stream, gx0, gx1, lds);
+        else        launch_generic_t<uint16_t, 64>(Lp, Rp, disp, cost, g, n, stream, gx0, gx1, lds);
     } else {
-        static bool attr32 = false;
-        if (!attr32) { (void)hipFuncSetAttribute((const void*)k_search_generic<uint32_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr32 = true; }
-        hipLaunchKernelGGL(k_search_generic<uint32_t>, grid, dim3(256), lds, stream, Lp, Rp, disp, cost, g);
+        if (narrow) launch_generic_t<uint32_t, 8>(Lp, Rp, disp, cost, g, n, stream, gx0, gx1, lds);
+        else        launch_generic_t<uint32_t, 64>(Lp, Rp, disp, cost, g, n, stream, gx0, gx1, lds);
     }
 }
 

@@ -225,21 +225,24 @@ static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane
     StageEvent ev;
     const bool fast = fast_search_supported(g);
     bool u16 = false;
-    if (!fast && !generic_search_supported(g, &u16)) return RTDM_ERR_UNSUPPORTED;
-    if (fast) {
-        bm->variant = "fast_qsad";
-        stage_begin(bm, RTDM_STAGE_SEARCH, n, s, &ev);
-        launch_search_fast(L, R, disp, bm->dCost, g, n, s);
-        stage_end(bm, s, &ev);
-    } else {
-        bm->variant = u16 ? "generic_u16" : "generic_u32";
+    if (!generic_search_supported(g, &u16)) return RTDM_ERR_UNSUPPORTED;
+    {
+        bm->variant = fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
         Plane8W Lp{bm->dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{bm->dRp, bm->ppitch, bm->ppitch * (size_t)H};
         stage_begin(bm, RTDM_STAGE_PREFILTER, n, s, &ev);
         launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s);
         stage_end(bm, s, &ev);
         Plane8 Lpr{bm->dLp, Lp.pitch, Lp.frame}, Rpr{bm->dRp, Rp.pitch, Rp.frame};
         stage_begin(bm, RTDM_STAGE_SEARCH, n, s, &ev);
-        launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s);
+        if (fast) {
+            int lx0, lx1, rx0, rx1;
+            fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
+            launch_search_fast(Lpr, Rpr, disp, bm->dCost, g, n, s);
+            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, lx0, lx1);
+            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, rx0, rx1);
+        } else {
+            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s);
+        }
         stage_end(bm, s, &ev);
     }
     if (p.disp12MaxDiff >= 0) {

@@ -36,13 +36,17 @@ void launch_fill16(Plane16W disp, int W, int H, int n, int value, hipStream_t st
 // K2 (generic variant): any D <= 256, any odd w, LDS column sums; writes disp (+ int32 cost).
 // Returns false if the configuration does not fit (caller reports RTDM_ERR_UNSUPPORTED).
 bool generic_search_supported(const BMGeom& g, bool* use16);
+// [gx0, gx1) restricts the output-column range (gx1 < 0: all of [0, width1)).
 void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g,
-                           int n, hipStream_t stream);
+                           int n, hipStream_t stream, int gx0 = 0, int gx1 = -1);
 
-// K2 (fast variant): packed-u8 quad-SAD kernel for the common configurations.
+// K2 (fast variant): packed-u8 quad-SAD kernel for the common configurations.  Works on the
+// prefiltered planes and covers the output columns whose window needs no border clamping; the
+// remaining border columns [lx0,lx1) and [rx0,rx1) go to the generic kernel.
 bool fast_search_supported(const BMGeom& g);
-void launch_search_fast(Plane8 L, Plane8 R, Plane16W disp, int32_t* cost, const BMGeom& g,
+void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g,
                         int n, hipStream_t stream);
+void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
 
 // K3: row-local left-right consistency check (+ column masking to the valid rectangle).
 void launch_lrcheck(Plane16W disp, const int32_t* cost, const BMGeom& g, int disp12MaxDiff, int n,
