@@ -1,0 +1,64 @@
+#include "hip_matcher_core.h"
+
+#include <cstdio>
+
+namespace rtdm {
+
+HIPMatcherCore::HIPMatcherCore(const Rect& roi1, const Rect& roi2, int preFilterCap, int blockSize, int minDisparity,
+                               int textureThreshold, int numOfDisparities, int maxDisparity, int uniquenessRatio,
+                               int speckleWindowSize, int speckleRange, int disp12MaxDiff,
+                               int maxWidth, int maxHeight, int maxBatch, int device)
+{
+    (void)roi1; (void)roi2; (void)maxDisparity;   // ignored by the reference constructor as well (bm-sw.cpp:12-26)
+    params_.preFilterCap = preFilterCap;
+    params_.blockSize = blockSize;
+    params_.minDisparity = minDisparity;
+    params_.numDisparities = numOfDisparities;
+    params_.textureThreshold = textureThreshold;
+    params_.uniquenessRatio = uniquenessRatio;
+    params_.speckleWindowSize = speckleWindowSize;
+    params_.speckleRange = speckleRange;
+    params_.disp12MaxDiff = disp12MaxDiff;
+    status_ = rtdm_bm_create(&params_, maxWidth, maxHeight, maxBatch, device, &bm_);
+    if (status_ != RTDM_OK)
+        std::fprintf(stderr, "HIPMatcher: %s%s%s\n", rtdm_strerror(status_),
+                     status_ == RTDM_ERR_HIP ? ": " : "", status_ == RTDM_ERR_HIP ? rtdm_last_hip_error() : "");
+}
+
+HIPMatcherCore::~HIPMatcherCore() { rtdm_bm_destroy(bm_); }
+
+void HIPMatcherCore::setROI1(const Rect& r) { if (bm_) status_ = rtdm_bm_set_roi(bm_, 1, r.x, r.y, r.width, r.height); }
+void HIPMatcherCore::setROI2(const Rect& r) { if (bm_) status_ = rtdm_bm_set_roi(bm_, 2, r.x, r.y, r.width, r.height); }
+
+int HIPMatcherCore::compute(const uint8_t* left, size_t leftStep, const uint8_t* right, size_t rightStep,
+                            int rows, int cols, int16_t* out, size_t outStep)
+{
+    if (!bm_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;   // loud: no CPU fallback
+    status_ = rtdm_bm_compute(bm_, left, leftStep, right, rightStep, cols, rows, out, outStep);
+    return status_;
+}
+
+int HIPMatcherCore::computeBatch(int n, const uint8_t* left, const uint8_t* right, size_t step, size_t frameStride,
+                                 int rows, int cols, int16_t* out, size_t outStep, size_t outFrameStride)
+{
+    if (!bm_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    status_ = rtdm_bm_compute_batch(bm_, n, left, right, step, frameStride, cols, rows, out, outStep, outFrameStride);
+    return status_;
+}
+
+HIPMorphCore::HIPMorphCore(int w, int h, int bpp, int device) : width_(w), height_(h), bpp_(bpp)
+{
+    status_ = (bpp == 8) ? rtdm_morph_create(w, h, 1, device, &mf_) : RTDM_ERR_UNSUPPORTED;
+    if (status_ != RTDM_OK) std::fprintf(stderr, "HIPMorphologicalFilter: %s\n", rtdm_strerror(status_));
+}
+HIPMorphCore::~HIPMorphCore() { rtdm_morph_destroy(mf_); }
+char* HIPMorphCore::getVideoInBuffer() { return (char*)rtdm_morph_in_buffer(mf_); }
+char* HIPMorphCore::getVideoOutBuffer() { return (char*)rtdm_morph_out_buffer(mf_); }
+int HIPMorphCore::run(const uint8_t* in, size_t inStep, uint8_t* out, size_t outStep, int rows, int cols)
+{
+    if (!mf_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    status_ = rtdm_morph_run(mf_, in, inStep, out, outStep, cols, rows);
+    return status_;
+}
+
+}  // namespace rtdm

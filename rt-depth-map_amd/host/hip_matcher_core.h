@@ -1,0 +1,74 @@
+// hip_matcher_core.h -- OpenCV-free C++ host layer over the C ABI (include/rtdm.h).
+//
+// HIPMatcherCore has the constructor shape, method names, argument meaning and error behaviour of
+// the reference's SWMatcherKonolige (/root/reference/include/stereo-matcher/bm-sw.h:28-35):
+// the same twelve constructor arguments in the same order (roi1, roi2 and maxDisparity are
+// accepted and ignored, as bm-sw.cpp:12-26 does), compute() returns an int that is 0 on success,
+// setROI1/setROI2 forward a rectangle.  The only differences are forced by the missing OpenCV:
+// images are (pointer, pitch, rows, cols) instead of cv::InputArray, rectangles are rtdm::Rect.
+// bm-hip.{h,cpp} wrap this class into the real `class HIPMatcher : public BlockMatcher`.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/rtdm.h"
+
+namespace rtdm {
+
+struct Rect { int x = 0, y = 0, width = 0, height = 0; };
+
+class HIPMatcherCore {
+public:
+    // Frame size is needed up front because the device buffers are allocated once, like the
+    // reference's FPGA matcher (bm-hw-ip.h:74: HWMatcherDisparityCoprocessor(name, width, height)).
+    HIPMatcherCore(const Rect& roi1, const Rect& roi2, int preFilterCap, int blockSize, int minDisparity,
+                   int textureThreshold, int numOfDisparities, int maxDisparity, int uniquenessRatio,
+                   int speckleWindowSize, int speckleRange, int disp12MaxDiff,
+                   int maxWidth, int maxHeight, int maxBatch = 1, int device = 0);
+    ~HIPMatcherCore();
+    HIPMatcherCore(const HIPMatcherCore&) = delete;
+    HIPMatcherCore& operator=(const HIPMatcherCore&) = delete;
+
+    void setROI1(const Rect& roi1);
+    void setROI2(const Rect& roi2);
+    // 8-bit single-channel inputs with free row pitch, 16-bit signed fixed-point (x16) output.
+    // Returns 0 on success, a negative rtdm_status otherwise (the reference's compute() returns
+    // int and its caller ignores it, estimator.cpp:56; nothing here throws).
+    int compute(const uint8_t* left, size_t leftStep, const uint8_t* right, size_t rightStep,
+                int rows, int cols, int16_t* out, size_t outStep);
+    // n contiguous frames (frameStride bytes apart), host memory, processed in device batches.
+    int computeBatch(int n, const uint8_t* left, const uint8_t* right, size_t step, size_t frameStride,
+                     int rows, int cols, int16_t* out, size_t outStep, size_t outFrameStride);
+
+    int status() const { return status_; }           // result of construction / last call
+    const char* statusText() const { return rtdm_strerror(status_); }
+    int filteredValue() const { return (params_.minDisparity - 1) * 16; }
+    rtdm_bm* handle() { return bm_; }
+
+private:
+    rtdm_bm_params params_;
+    rtdm_bm* bm_ = nullptr;
+    int status_ = RTDM_OK;
+};
+
+// VideoFilterDevice counterpart (/root/reference/include/filter/filter.h:13-37,
+// /root/reference/filter/mf-sw.cpp:10-28): owns the frame buffers it hands out.
+class HIPMorphCore {
+public:
+    HIPMorphCore(int w, int h, int bpp, int device = 0);
+    ~HIPMorphCore();
+    HIPMorphCore(const HIPMorphCore&) = delete;
+    HIPMorphCore& operator=(const HIPMorphCore&) = delete;
+    char* getVideoInBuffer();
+    char* getVideoOutBuffer();
+    int getFrameSize() const { return width_ * height_ * (bpp_ >> 3); }
+    int run(const uint8_t* in, size_t inStep, uint8_t* out, size_t outStep, int rows, int cols);
+    int status() const { return status_; }
+
+private:
+    rtdm_morph* mf_ = nullptr;
+    int width_, height_, bpp_, status_ = RTDM_OK;
+};
+
+}  // namespace rtdm

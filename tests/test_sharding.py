@@ -1,0 +1,74 @@
+"""Multi-GPU path on CPU: world_size-2 (and 3) gloo runs of the whole-frame sharding.  The compute
+callable is the oracle here (tests may use it); on the GPU box the same function wraps the HIP
+matcher.  Property: the gathered N-rank output is byte-identical to the 1-rank output."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load
+
+W, H, D, NF = 96, 64, 16, 7
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _oracle_compute(L, R):
+    from oracle import oracle as orc
+    out = [orc.bm_compute(l.numpy(), r.numpy(), numDisparities=D, blockSize=7) for l, r in zip(L, R)]
+    return torch.from_numpy(np.stack(out))
+
+
+def _worker(rank, world, port, chunk, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = load()
+    sh = load("sharding")
+    left = right = None
+    if rank == 0:
+        L, R = pkg.synth.make_stream(0, NF, W, H, D)
+        left, right = torch.from_numpy(L), torch.from_numpy(R)
+    out = sh.scatter_compute_gather(dist, left, right, NF, (H, W), _oracle_compute, torch.device("cpu"), chunk=chunk)
+    # comm-free mode: every rank makes its own frames; rank 0 checks its block against the stream
+    first, cnt = sh.local_stream(0, NF, world, rank)
+    Lr, Rr = pkg.synth.make_stream(first, cnt, W, H, D)
+    mine = _oracle_compute(torch.from_numpy(Lr), torch.from_numpy(Rr))
+    blocks = [None] * world
+    dist.all_gather_object(blocks, mine.numpy())
+    if rank == 0:
+        q.put((out.numpy(), np.concatenate(blocks)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,chunk", [(2, None), (2, 2), (3, None)])
+def test_sharded_equals_single_rank(world, chunk):
+    pkg = load()
+    L, R = pkg.synth.make_stream(0, NF, W, H, D)
+    ref = _oracle_compute(torch.from_numpy(L), torch.from_numpy(R)).numpy()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, chunk, q)) for r in range(world)]
+    [p.start() for p in procs]
+    gathered, commfree = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert np.array_equal(gathered, ref)
+    assert np.array_equal(commfree, ref)
+
+
+def test_partition_is_a_contiguous_cover():
+    sh = load("sharding")
+    for n in (1, 7, 128, 1024):
+        for world in (1, 2, 3, 8):
+            spans = [sh.partition(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            for (s0, c0), (s1, _) in zip(spans, spans[1:]):
+                assert s0 + c0 == s1
+    assert sh.shard_sizes(1024, 8) == [128] * 8
