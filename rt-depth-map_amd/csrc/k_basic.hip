@@ -7,150 +7,166 @@
 namespace rtdm {
 
 // ---------------------------------------------------------------------------------------------
-// K1 prefilter: one thread = 4 consecutive output bytes of one row (dword store).
-// Rows come in pairs; a trailing odd row is all `cap`; row -1 mirrors to 1, row H to H-2.
+// K1 prefilter: x-Sobel, clip to +-cap, + cap.  Rows come in pairs; a trailing odd row is all
+// `cap`; row -1 mirrors to 1, row H to H-2; columns 0 and W-1 are `cap`.
+// Fast variant: one thread = 8 consecutive output bytes from three 8-byte loads per source row
+// (needs 8-byte aligned base/pitch/frame); byte variant for arbitrary caller pitches.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp,
-                                                   int W, int H, int cap, int n)
+__device__ __forceinline__ int colsum3(unsigned long long a, unsigned long long c, unsigned long long b, int k)
+{ return (int)((a >> (8 * k)) & 0xff) + 2 * (int)((c >> (8 * k)) & 0xff) + (int)((b >> (8 * k)) & 0xff); }
+
+__global__ __launch_bounds__(256) void k_prefilter8(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp,
+                                                    int W, int H, int cap, int n, int nxb)
 {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int y = blockIdx.y;
-    int f = blockIdx.z;
-    if (x0 >= W) return;
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // over (row, 8-byte block)
+    if (idx >= nxb * H) return;
+    const int y = idx / nxb, xb = idx - y * nxb, x0 = xb * 8;
+    int f = blockIdx.y;
     const bool right = f >= n;
     if (right) f -= n;
     const Plane8 S = right ? R : L;
     const Plane8W O = right ? Rp : Lp;
     const uint8_t* src = S.base + (size_t)f * S.frame;
-    uint8_t* dst = O.base + (size_t)f * O.frame + (size_t)y * O.pitch;
+    uint8_t* dst = O.base + (size_t)f * O.frame + (size_t)y * O.pitch + x0;
     const int npair = (H >= 2) ? (H & ~1) : 0;
-    uint8_t out[4];
-    if (y >= npair) {
+    unsigned long long out = (unsigned long long)cap * 0x0101010101010101ull;
+    if (y < npair) {
+        const int ya = (y > 0) ? y - 1 : 1;
+        const int yb = (y < H - 1) ? y + 1 : H - 2;
+        const uint8_t* ra = src + (size_t)ya * S.pitch + x0;
+        const uint8_t* rc = src + (size_t)y * S.pitch + x0;
+        const uint8_t* rb = src + (size_t)yb * S.pitch + x0;
+        const bool has_prev = x0 > 0, has_next = x0 + 16 <= (int)S.pitch;
+        const unsigned long long a1 = *(const unsigned long long*)ra, c1 = *(const unsigned long long*)rc,
+                                 b1 = *(const unsigned long long*)rb;
+        const unsigned long long a0 = has_prev ? *(const unsigned long long*)(ra - 8) : 0ull,
+                                 c0 = has_prev ? *(const unsigned long long*)(rc - 8) : 0ull,
+                                 b0 = has_prev ? *(const unsigned long long*)(rb - 8) : 0ull;
+        const unsigned long long a2 = has_next ? *(const unsigned long long*)(ra + 8) : 0ull,
+                                 c2 = has_next ? *(const unsigned long long*)(rc + 8) : 0ull,
+                                 b2 = has_next ? *(const unsigned long long*)(rb + 8) : 0ull;
+        int s[10];                                          // column sums for x0-1 .. x0+8
+        s[0] = colsum3(a0, c0, b0, 7);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) out[k] = (uint8_t)cap;
-    } else {
+        for (int k = 0; k < 8; ++k) s[k + 1] = colsum3(a1, c1, b1, k);
+        s[9] = colsum3(a2, c2, b2, 0);
+        out = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int x = x0 + k;
+            int g = s[k + 2] - s[k];
+            g = g < -cap ? -cap : (g > cap ? cap : g);
+            const int v = (x == 0 || x >= W - 1) ? cap : g + cap;
+            out |= (unsigned long long)v << (8 * k);
+        }
+    }
+    *(unsigned long long*)dst = out;                        // plane pitch is a multiple of 64: in bounds
+}
+
+__global__ __launch_bounds__(256) void k_prefilter1(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp,
+                                                    int W, int H, int cap, int n)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    int f = blockIdx.z;
+    if (x >= W) return;
+    const bool right = f >= n;
+    if (right) f -= n;
+    const Plane8 S = right ? R : L;
+    const Plane8W O = right ? Rp : Lp;
+    const uint8_t* src = S.base + (size_t)f * S.frame;
+    const int npair = (H >= 2) ? (H & ~1) : 0;
+    int v = cap;
+    if (y < npair && x > 0 && x < W - 1) {
         const int ya = (y > 0) ? y - 1 : 1;
         const int yb = (y < H - 1) ? y + 1 : H - 2;
         const uint8_t* ra = src + (size_t)ya * S.pitch;
         const uint8_t* rc = src + (size_t)y * S.pitch;
         const uint8_t* rb = src + (size_t)yb * S.pitch;
-        // column sums s(x) = a + 2c + b for x0-1 .. x0+4 (clamped reads; clamped columns are
-        // only consumed by outputs that are forced to `cap` anyway)
-        int s[6];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            int x = x0 - 1 + k;
-            x = x < 0 ? 0 : (x > W - 1 ? W - 1 : x);
-            s[k] = (int)ra[x] + 2 * (int)rc[x] + (int)rb[x];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int x = x0 + k;
-            int g = s[k + 2] - s[k];
-            g = g < -cap ? -cap : (g > cap ? cap : g);
-            out[k] = (x == 0 || x >= W - 1) ? (uint8_t)cap : (uint8_t)(g + cap);
-        }
+        int g = ((int)ra[x + 1] - (int)ra[x - 1]) + 2 * ((int)rc[x + 1] - (int)rc[x - 1]) + ((int)rb[x + 1] - (int)rb[x - 1]);
+        g = g < -cap ? -cap : (g > cap ? cap : g);
+        v = g + cap;
     }
-    if (x0 + 3 < W && ((O.pitch & 3) == 0)) {
-        *(uint32_t*)(dst + x0) = (uint32_t)out[0] | ((uint32_t)out[1] << 8) | ((uint32_t)out[2] << 16) |
-                                 ((uint32_t)out[3] << 24);
-    } else {
-        for (int k = 0; k < 4 && x0 + k < W; ++k) dst[x0 + k] = out[k];
-    }
+    O.base[(size_t)f * O.frame + (size_t)y * O.pitch + x] = (uint8_t)v;
 }
 
 void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, int cap, int n,
                       hipStream_t stream)
 {
-    dim3 grid((W + 1023) / 1024, H, 2 * n);
-    hipLaunchKernelGGL(k_prefilter, grid, dim3(256), 0, stream, L, R, Lp, Rp, W, H, cap, n);
-}
-
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_fill16(Plane16W d, int W, int H, int value)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
-    d.base[(size_t)blockIdx.z * d.frame_e + (size_t)blockIdx.y * d.pitch_e + x] = (int16_t)value;
-}
-
-void launch_fill16(Plane16W disp, int W, int H, int n, int value, hipStream_t stream)
-{
-    hipLaunchKernelGGL(k_fill16, dim3((W + 255) / 256, H, n), dim3(256), 0, stream, disp, W, H, value);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3 left-right check: one workgroup per (valid row, frame).  LDS holds a snapshot of the row and
-// one 64-bit key per column: (cost << 32 | x); ds_min_u64 reproduces validateDisparity's pass 1
-// ("strictly smaller cost wins, first x wins ties").  Pass 2 reads the snapshot, so the in-place
-// update cannot race.  Columns outside the valid rectangle are masked in the same pass.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const int32_t* cost, BMGeom g, int maxDiff16)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* key = (unsigned long long*)smem;            // W
-    int16_t* snap = (int16_t*)(smem + (size_t)g.W * 8);             // W
-    const int y = g.vy0 + blockIdx.y;
-    const int f = blockIdx.z;
-    int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const int32_t* crow = cost + ((size_t)f * g.H + y) * g.W;
-    const int W = g.W, INV = g.filtered;
-    for (int x = threadIdx.x; x < W; x += 256) { key[x] = ~0ull; snap[x] = row[x]; }
-    __syncthreads();
-    const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
-    for (int x = minX1 + threadIdx.x; x < maxX1; x += 256) {
-        const int d = snap[x];
-        if (d == INV) continue;
-        const int x2 = x - ((d + 8) >> 4);
-        if (x2 < 0 || x2 >= W) continue;
-        const unsigned long long k = ((unsigned long long)(unsigned)crow[x] << 32) | (unsigned)x;
-        atomicMin(&key[x2], k);
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256) {
-        int d = snap[x];
-        bool kill = (x < g.vx0 || x >= g.vx1);
-        if (!kill && d != INV && x >= minX1 && x < maxX1) {
-            const int x0 = x - (d >> 4), x1 = x - ((d + 15) >> 4);
-            bool bad0 = false, bad1 = false;
-            if (x0 >= 0 && x0 < W && key[x0] != ~0ull) {
-                const int d2 = snap[(unsigned)(key[x0] & 0xffffffffu)];
-                bad0 = abs(d2 - d) > maxDiff16;
-            }
-            if (x1 >= 0 && x1 < W && key[x1] != ~0ull) {
-                const int d2 = snap[(unsigned)(key[x1] & 0xffffffffu)];
-                bad1 = abs(d2 - d) > maxDiff16;
-            }
-            kill = bad0 && bad1;
-        }
-        if (kill && d != INV) row[x] = (int16_t)INV;
+    const auto al8 = [](const Plane8& p) { return (((size_t)p.base | p.pitch | p.frame) & 7) == 0; };
+    if (al8(L) && al8(R) && L.pitch >= (size_t)((W + 7) & ~7) && R.pitch >= (size_t)((W + 7) & ~7)) {
+        const int nxb = (W + 7) / 8;
+        hipLaunchKernelGGL(k_prefilter8, dim3((nxb * H + 255) / 256, 2 * n), dim3(256), 0, stream, L, R, Lp, Rp, W, H, cap, n, nxb);
+    } else {
+        hipLaunchKernelGGL(k_prefilter1, dim3((W + 255) / 256, H, 2 * n), dim3(256), 0, stream, L, R, Lp, Rp, W, H, cap, n);
     }
 }
 
-void launch_lrcheck(Plane16W disp, const int32_t* cost, const BMGeom& g, int disp12MaxDiff, int n,
-                    hipStream_t stream)
+// ---------------------------------------------------------------------------------------------
+// FILTERED fill of a rectangle [x0,x1) x [y0,y1) of every frame (16 pixels per thread).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fill16(Plane16W d, int x0, int x1, int y0, int y1, int value)
 {
-    const size_t lds = (size_t)g.W * 10;
-    hipLaunchKernelGGL(k_lrcheck, dim3(1, g.vy1 - g.vy0, n), dim3(256), lds, stream, disp, cost, g,
-                       disp12MaxDiff * 16);
+    const int nxb = (x1 - x0 + 15) / 16;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nxb * (y1 - y0)) return;
+    const int y = y0 + idx / nxb, xs = x0 + (idx % nxb) * 16;
+    int16_t* p = d.base + (size_t)blockIdx.y * d.frame_e + (size_t)y * d.pitch_e;
+    for (int x = xs; x < min(xs + 16, x1); ++x) p[x] = (int16_t)value;
+}
+
+void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int value, hipStream_t stream)
+{
+    if (x1 <= x0 || y1 <= y0) return;
+    const int nxb = (x1 - x0 + 15) / 16;
+    hipLaunchKernelGGL(k_fill16, dim3((nxb * (y1 - y0) + 255) / 256, n), dim3(256), 0, stream, disp, x0, x1, y0, y1, value);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4 speckle filter (cv::filterSpeckles as called by cv::StereoBM::compute, SURVEY.md Appendix
-// A.5): 4-connected components of pixels != newVal under |a-b| <= maxDiff; components with
-// size <= maxSize become newVal.  Run-based union-find:
-//   init   one workgroup per row: a max-scan turns the "connected to my left neighbour" flags into
-//          run heads; every pixel of a horizontal run is represented by its head, which starts as
-//          its own parent and carries the run length.
-//   merge  one workgroup per row pair: ONE union per vertical contact segment between two runs
-//          (a pixel is skipped when its left neighbour already linked the same two runs).
-//   count  every non-root head adds its run length to its root (skipped once the root is known to
-//          be large: only "<= maxSize" matters) and is re-pointed straight at the root.
-//   apply  one workgroup per row: heads chase to their root, look its size up once, pixels read the flag.
-// Parent pointers only ever move to smaller indices of the same component and every hook is a
-// device-scope atomicMin on a root, so stale reads are still ancestors and the set of small
-// components is independent of scheduling.  Components never span frames.
+// Shared helpers for the row kernels: workgroup scans over a row held in LDS (256 threads,
+// contiguous chunk per thread), union-find primitives.
 // ---------------------------------------------------------------------------------------------
+// Scan element = (number of run heads so far) << 16 | (x of the nearest head to the left + 1):
+// one pass yields both the head of every pixel and the compact index of every run.
+struct OpHead {
+    static __device__ int id() { return 0; }
+    static __device__ int f(int a, int b) { return (int)(((unsigned)a & 0xffff0000u) + ((unsigned)b & 0xffff0000u)) | max(a & 0xffff, b & 0xffff); }
+};
+
+// Inclusive scan of v[0..W) (int32 in LDS) in place.  Whole workgroup; ends with a barrier.
+template <typename Op>
+__device__ __forceinline__ void row_scan(int* v, int W, int* wsum)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int CH = (W + 255) >> 8;
+    const int x0 = tid * CH;
+    int run = Op::id();
+    for (int k = 0; k < CH; ++k) {
+        const int x = x0 + k;
+        if (x < W) { run = Op::f(run, v[x]); v[x] = run; }
+    }
+    int t = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(t, o);
+        if (lane >= o) t = Op::f(t, u);
+    }
+    __syncthreads();                 // previous users of wsum are done
+    if (lane == 63) wsum[wv] = t;
+    __syncthreads();
+    int excl = __shfl_up(t, 1);
+    if (lane == 0) excl = Op::id();
+    for (int q = 0; q < wv; ++q) excl = Op::f(excl, wsum[q]);
+    for (int k = 0; k < CH; ++k) {
+        const int x = x0 + k;
+        if (x < W) v[x] = Op::f(v[x], excl);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool conn(int a, int b, int newVal, int maxDiff)
+{ return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
+
 __device__ __forceinline__ int ld_relaxed(const int32_t* p)
 { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_relaxed(int32_t* p, int v)
@@ -181,154 +197,237 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b)
     }
 }
 
-// Inclusive max-scan over hp[0..W) (LDS, int16: x at run heads, -1 elsewhere), 256 threads,
-// contiguous chunks per thread.  Must be called by the whole workgroup; ends with a barrier.
-__device__ __forceinline__ void head_scan(int16_t* hp, int W, int* wsum)
+// Speckle "init" for one row held in LDS (d[0..W)): finds the horizontal runs, makes every run head
+// its own parent with the run length as its size, appends (x | len << 16) to the row's run list and
+// writes the per-pixel head map (x of the run head, int16) that the merge step reads.
+// sc is a W-element int32 scratch array.  Whole workgroup.
+__device__ __forceinline__ void spk_row_init(const int16_t* d, int* sc, int* wsum, int W, int base,
+                                             int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                                             int16_t* headmap, int newVal, int maxDiff)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int CH = (W + 255) >> 8;
-    const int x0 = tid * CH;
-    int run = -1;
-    for (int k = 0; k < CH; ++k) {
-        const int x = x0 + k;
-        if (x < W) { run = max(run, (int)hp[x]); hp[x] = (int16_t)run; }
-    }
-    int v = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(v, o);
-        if (lane >= o) v = max(v, u);
-    }
-    if (lane == 63) wsum[wv] = v;
-    __syncthreads();
-    int excl = __shfl_up(v, 1);
-    if (lane == 0) excl = -1;
-    for (int q = 0; q < wv; ++q) excl = max(excl, wsum[q]);
-    for (int k = 0; k < CH; ++k) {
-        const int x = x0 + k;
-        if (x < W) hp[x] = (int16_t)max((int)hp[x], excl);
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ bool conn(int a, int b, int newVal, int maxDiff)
-{ return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
-
-__global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label, int32_t* size, int W, int H,
-                                                  int newVal, int maxDiff)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int16_t* d = (int16_t*)smem;          // W
-    int16_t* hp = d + W;                  // W
-    __shared__ int wsum[4];
-    const int y = blockIdx.y, f = blockIdx.z;
-    const int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const int base = (f * H + y) * W;
-    for (int x = threadIdx.x; x < W; x += 256) d[x] = row[x];
-    __syncthreads();
     for (int x = threadIdx.x; x < W; x += 256) {
         const int v = d[x];
         const bool head = v != newVal && !(x > 0 && conn(v, d[x - 1], newVal, maxDiff));
-        hp[x] = head ? (int16_t)x : (int16_t)-1;
+        sc[x] = head ? ((1 << 16) | (x + 1)) : 0;
     }
     __syncthreads();
-    head_scan(hp, W, wsum);
+    row_scan<OpHead>(sc, W, wsum);
     for (int x = threadIdx.x; x < W; x += 256) {
         const int v = d[x];
+        const int h = (sc[x] & 0xffff) - 1;
+        headmap[base + x] = (int16_t)h;
         if (v == newVal) continue;
-        const int h = hp[x];
-        if (h == x) label[base + x] = base + x;
         const bool last = (x == W - 1) || !conn(v, d[x + 1], newVal, maxDiff);
-        if (last) size[base + h] = x - h + 1;
+        if (!last) continue;
+        const int len = x - h + 1;
+        label[base + h] = base + h;
+        size[base + h] = len;
+        runs[base + (sc[x] >> 16) - 1] = (uint32_t)h | ((uint32_t)len << 16);
     }
+    if (threadIdx.x == 0) *rowcnt = sc[W - 1] >> 16;
 }
 
-__global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, int W, int H, int newVal, int maxDiff)
+// ---------------------------------------------------------------------------------------------
+// K3 left-right check (cv::validateDisparity): one workgroup per (valid
+// row, frame).  LDS holds a snapshot of the row and one 64-bit key per column: (cost << 32 | x);
+// ds_min_u64 reproduces pass 1 ("strictly smaller cost wins, first x wins ties").  Pass 2 reads the
+// snapshot, so the in-place update cannot race.  Columns outside the valid rectangle are masked in
+// the same pass.  With SPK the final row is handed straight to the speckle filter's init step.
+// ---------------------------------------------------------------------------------------------
+template <bool SPK, typename CT>
+__global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, BMGeom g, int maxDiff16,
+                                                 int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                                                 int16_t* headmap, int spkDiff)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int16_t* d0 = (int16_t*)smem;
-    int16_t* d1 = d0 + W;
-    int16_t* h0 = d1 + W;
-    int16_t* h1 = h0 + W;
+    unsigned long long* key = (unsigned long long*)smem;            // W
+    int16_t* snap = (int16_t*)(smem + (size_t)g.W * 8);             // W
+    int16_t* fin = snap + g.W;                                      // W (final row)
     __shared__ int wsum[4];
-    const int y = blockIdx.y, f = blockIdx.z;      // rows y and y+1
-    const int16_t* r0 = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const int16_t* r1 = r0 + disp.pitch_e;
-    const int base0 = (f * H + y) * W, base1 = base0 + W;
-    for (int x = threadIdx.x; x < W; x += 256) { d0[x] = r0[x]; d1[x] = r1[x]; }
+    const int y = g.vy0 + blockIdx.y;
+    const int f = blockIdx.z;
+    int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    const CT* crow = cost + ((size_t)f * g.H + y) * g.W;
+    const int W = g.W, INV = g.filtered;
+    for (int x = threadIdx.x; x < W; x += 256) { key[x] = ~0ull; snap[x] = row[x]; }
     __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256) {
-        const int a = d0[x], b = d1[x];
-        h0[x] = (a != newVal && !(x > 0 && conn(a, d0[x - 1], newVal, maxDiff))) ? (int16_t)x : (int16_t)-1;
-        h1[x] = (b != newVal && !(x > 0 && conn(b, d1[x - 1], newVal, maxDiff))) ? (int16_t)x : (int16_t)-1;
+    const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
+    for (int x = minX1 + threadIdx.x; x < maxX1; x += 256) {
+        const int d = snap[x];
+        if (d == INV) continue;
+        const int x2 = x - ((d + 8) >> 4);
+        if (x2 < 0 || x2 >= W) continue;
+        const unsigned long long k = ((unsigned long long)(unsigned)crow[x] << 32) | (unsigned)x;
+        atomicMin(&key[x2], k);
     }
     __syncthreads();
-    head_scan(h0, W, wsum);
-    head_scan(h1, W, wsum);
     for (int x = threadIdx.x; x < W; x += 256) {
-        if (!conn(d0[x], d1[x], newVal, maxDiff)) continue;
-        const bool dup = x > 0 && conn(d0[x - 1], d1[x - 1], newVal, maxDiff) && h0[x - 1] == h0[x] && h1[x - 1] == h1[x];
-        if (!dup) uf_union(label, base0 + h0[x], base1 + h1[x]);
+        int d = snap[x];
+        bool kill = (x < g.vx0 || x >= g.vx1);
+        if (!kill && d != INV && x >= minX1 && x < maxX1) {
+            const int x0 = x - (d >> 4), x1 = x - ((d + 15) >> 4);
+            bool bad0 = false, bad1 = false;
+            if (x0 >= 0 && x0 < W && key[x0] != ~0ull) {
+                const int d2 = snap[(unsigned)(key[x0] & 0xffffffffu)];
+                bad0 = abs(d2 - d) > maxDiff16;
+            }
+            if (x1 >= 0 && x1 < W && key[x1] != ~0ull) {
+                const int d2 = snap[(unsigned)(key[x1] & 0xffffffffu)];
+                bad1 = abs(d2 - d) > maxDiff16;
+            }
+            kill = bad0 && bad1;
+        }
+        if (kill && d != INV) { row[x] = (int16_t)INV; d = INV; }
+        if (SPK) fin[x] = (int16_t)d;
+    }
+    if (SPK) {
+        __syncthreads();
+        const int base = (f * g.H + y) * W;               // the keys are no longer needed: scan scratch
+        spk_row_init(fin, (int*)key, wsum, W, base, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff);
     }
 }
 
-__global__ __launch_bounds__(256) void k_spk_count(Plane16W disp, int32_t* label, int32_t* size, int W, int H,
-                                                   int newVal, int maxDiff, int maxSize)
+void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
+                    hipStream_t stream, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                    int16_t* headmap, int spkDiff)
 {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    if (x >= W) return;
+    const size_t lds = (size_t)g.W * 12;
+    dim3 grid(1, g.vy1 - g.vy0, n), block(256);
+    const int md = disp12MaxDiff * 16;
+    if (g.cost16) {
+        const uint16_t* c = (const uint16_t*)cost;
+        if (label) hipLaunchKernelGGL((k_lrcheck<true, uint16_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL((k_lrcheck<false, uint16_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+    } else {
+        const int32_t* c = (const int32_t*)cost;
+        if (label) hipLaunchKernelGGL((k_lrcheck<true, int32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL((k_lrcheck<false, int32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4 speckle filter (cv::filterSpeckles as called by cv::StereoBM::compute, SURVEY.md Appendix
+// A.5): 4-connected components of pixels != newVal under |a-b| <= maxDiff; components with
+// size <= maxSize become newVal.  Run-based union-find:
+//   init   (fused into k_lrcheck, or k_spk_init when the left-right check is off) per row: a
+//          max-scan turns the "connected to my left neighbour" flags into run heads; every pixel of
+//          a horizontal run is represented by its head, which starts as its own parent and carries
+//          the run length; the row's runs are also listed compactly (x | len << 16).
+//   merge  one workgroup per block of rows: ONE union per vertical contact segment between two
+//          runs (a pixel is skipped when its left neighbour already linked the same two runs).
+//   count  one wave per row, lanes over its runs: every non-root head adds its run length to its
+//          root (skipped once the root is known to be large: only "<= maxSize" matters).
+//   apply  one wave per row, lanes over its runs: a run whose root is small is overwritten.
+// Parent pointers only ever move to smaller indices of the same component and every hook is a
+// device-scope atomicMin on a root, so stale reads are still ancestors and the set of small
+// components is independent of scheduling.  Components never span frames.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs,
+                                                  int32_t* rowcnt, int16_t* headmap, int W, int H, int newVal, int maxDiff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sc = (int*)smem;                 // W
+    int16_t* d = (int16_t*)(sc + W);      // W
+    __shared__ int wsum[4];
     const int y = blockIdx.y, f = blockIdx.z;
     const int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const int v = row[x];
-    if (v == newVal) return;
-    if (x > 0 && conn(v, row[x - 1], newVal, maxDiff)) return;      // not a run head
-    const int idx = (f * H + y) * W + x;
-    const int root = uf_find(label, idx);
-    if (root == idx) return;
-    st_relaxed(&label[idx], root);             // roots are final in this launch
-    if (ld_relaxed(&size[root]) <= maxSize) atomicAdd(&size[root], size[idx]);
+    for (int x = threadIdx.x; x < W; x += 256) d[x] = row[x];
+    __syncthreads();
+    spk_row_init(d, sc, wsum, W, (f * H + y) * W, label, size, runs, rowcnt + (f * H + y), headmap, newVal, maxDiff);
+}
+
+// merge: one thread = 8 consecutive pixels of a row pair (y, y+1); no LDS, no scans: the heads come
+// from the head map.  A pixel is skipped when its left neighbour already linked the same two runs.
+__global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int H,
+                                                   int y_lo, int y_hi, int newVal, int maxDiff)
+{
+    const int nxb = (W + 7) / 8;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nxb * (y_hi - y_lo)) return;
+    const int y = y_lo + idx / nxb, x0 = (idx % nxb) * 8;
+    const int f = blockIdx.y;
+    const int16_t* d0 = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    const int16_t* d1 = d0 + disp.pitch_e;
+    const int base0 = (f * H + y) * W, base1 = base0 + W;
+    const int16_t* h0 = headmap + base0;
+    const int16_t* h1 = headmap + base1;
+    int pa = newVal, pb = newVal, ph0 = -1, ph1 = -1;       // left neighbour state
+    bool pc = false;
+    if (x0 > 0) {
+        pa = d0[x0 - 1]; pb = d1[x0 - 1];
+        pc = conn(pa, pb, newVal, maxDiff);
+        if (pc) { ph0 = h0[x0 - 1]; ph1 = h1[x0 - 1]; }
+    }
+    for (int x = x0; x < min(x0 + 8, W); ++x) {
+        const int a = d0[x], b = d1[x];
+        const bool c = conn(a, b, newVal, maxDiff);
+        int ha = -1, hb = -1;
+        if (c) {
+            ha = h0[x]; hb = h1[x];
+            if (!(pc && ph0 == ha && ph1 == hb)) uf_union(label, base0 + ha, base1 + hb);
+        }
+        pc = c; ph0 = ha; ph1 = hb;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, const uint32_t* runs,
+                                                   const int32_t* rowcnt, int W, int nrows, int maxSize)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);        // one wave per row of the batch
+    if (row >= nrows) return;
+    const int cnt = rowcnt[row], base = row * W;
+    for (int i = threadIdx.x & 63; i < cnt; i += 64) {
+        const uint32_t rn = runs[base + i];
+        const int idx = base + (int)(rn & 0xffffu), len = (int)(rn >> 16);
+        const int root = uf_find(label, idx);
+        if (root == idx) continue;
+        st_relaxed(&label[idx], root);             // roots are final in this launch
+        if (ld_relaxed(&size[root]) <= maxSize) atomicAdd(&size[root], len);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t* label, const int32_t* size,
-                                                   int W, int H, int newVal, int maxDiff, int maxSize)
+                                                   const uint32_t* runs, const int32_t* rowcnt, int W, int H, int nrows,
+                                                   int newVal, int maxSize)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int16_t* d = (int16_t*)smem;          // W
-    int16_t* hp = d + W;                  // W
-    uint8_t* small = (uint8_t*)(hp + W);  // W
-    __shared__ int wsum[4];
-    const int y = blockIdx.y, f = blockIdx.z;
-    int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const int base = (f * H + y) * W;
-    for (int x = threadIdx.x; x < W; x += 256) d[x] = row[x];
-    __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256) {
-        const int v = d[x];
-        const bool head = v != newVal && !(x > 0 && conn(v, d[x - 1], newVal, maxDiff));
-        hp[x] = head ? (int16_t)x : (int16_t)-1;
-        if (head) {
-            // after k_spk_count a head is at most a couple of hops from its root (a late path-halving
-            // store of another thread may have left an ancestor instead of the root), so chase it
-            int root = base + x;
-            for (int p = label[root]; p != root; p = label[root]) root = p;
-            small[x] = size[root] <= maxSize;
-        }
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const int cnt = rowcnt[row], base = row * W;
+    const int f = row / H, y = row - f * H;
+    int16_t* drow = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    for (int i = threadIdx.x & 63; i < cnt; i += 64) {
+        const uint32_t rn = runs[base + i];
+        const int x = (int)(rn & 0xffffu), len = (int)(rn >> 16);
+        // after k_spk_count a head is at most a couple of hops from its root (a late path-halving
+        // store of another thread may have left an ancestor instead of the root), so chase it
+        int root = base + x;
+        for (int p = label[root]; p != root; p = label[root]) root = p;
+        if (size[root] <= maxSize)
+            for (int k = 0; k < len; ++k) drow[x + k] = (int16_t)newVal;
     }
-    __syncthreads();
-    head_scan(hp, W, wsum);
-    for (int x = threadIdx.x; x < W; x += 256)
-        if (d[x] != newVal && small[hp[x]]) row[x] = (int16_t)newVal;
 }
 
-void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, int W, int H, int n, int newVal,
-                    int maxSize, int maxDiff, hipStream_t stream)
+// label/size/runs/headmap: n*W*H elements each; rowcnt: n*H.  If init_done, the rows [y_lo, y_hi) were
+// initialised by k_lrcheck<true> (rowcnt was zeroed before it) and no other row holds a valid pixel.
+void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
+                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int y_lo, int y_hi,
+                    hipStream_t stream)
 {
-    dim3 rows(1, H, n), block(256);
-    hipLaunchKernelGGL(k_spk_init, rows, block, (size_t)W * 4, stream, disp, label, size, W, H, newVal, maxDiff);
-    if (H > 1)
-        hipLaunchKernelGGL(k_spk_merge, dim3(1, H - 1, n), block, (size_t)W * 8, stream, disp, label, W, H, newVal, maxDiff);
-    hipLaunchKernelGGL(k_spk_count, dim3((W + 255) / 256, H, n), block, 0, stream, disp, label, size, W, H, newVal, maxDiff, maxSize);
-    hipLaunchKernelGGL(k_spk_apply, rows, block, (size_t)W * 5, stream, disp, label, size, W, H, newVal, maxDiff, maxSize);
+    dim3 block(256);
+    if (!init_done) {
+        y_lo = 0; y_hi = H;
+        hipLaunchKernelGGL(k_spk_init, dim3(1, H, n), block, (size_t)W * 6, stream, disp, label, size, runs, rowcnt, headmap,
+                           W, H, newVal, maxDiff);
+    }
+    const int pairs_hi = min(y_hi, H) - 1;           // pairs (y, y+1) with both rows initialised
+    if (pairs_hi > y_lo) {
+        const int nxb = (W + 7) / 8;
+        hipLaunchKernelGGL(k_spk_merge, dim3((nxb * (pairs_hi - y_lo) + 255) / 256, n), block, 0, stream, disp, label, headmap,
+                           W, H, y_lo, pairs_hi, newVal, maxDiff);
+    }
+    const int nrows = n * H;
+    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 3) / 4), block, 0, stream, label, size, runs, rowcnt, W, nrows, maxSize);
+    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 3) / 4), block, 0, stream, disp, label, size, runs, rowcnt, W, H, nrows, newVal, maxSize);
 }
 
 }  // namespace rtdm

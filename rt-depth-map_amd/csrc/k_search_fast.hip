@@ -20,6 +20,8 @@
 //   left-right check).  Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
 #include "rtdm_kernels.h"
 
+#include <cstdlib>
+
 namespace rtdm {
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
@@ -97,7 +99,7 @@ __device__ __forceinline__ int div_trunc_small(int num, int den)   // den > 0, |
 }
 
 template <int D, int NP>
-__global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost,
+__global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
                                                      BMGeom g, FastGeom fg)
 {
     using C = FastCfg<D, NP>;
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
                 out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
             }
             if (active) {
-                if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = m1;
+                if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = (uint16_t)m1;
                 db[(size_t)y * disp.pitch_e + col] = (int16_t)(masked_col ? g.filtered : out);
             }
         }
@@ -295,7 +297,7 @@ static bool fast_range(const BMGeom& g, int* x0, int* nx)
 static int fast_np(const BMGeom& g) { return (g.w + 3) / 4; }
 
 template <int D, int NP>
-static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g, int n, hipStream_t stream)
+static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream)
 {
     using C = FastCfg<D, NP>;
     FastGeom fg;
@@ -304,14 +306,18 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const
     fg.lastmask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
     const int nrows = g.vy1 - g.vy0;
     const int tiles = (fg.nx + 255) / 256;
-    int strips = (2048 + tiles * n - 1) / (tiles * n);
-    strips = max(1, min(strips, (nrows + 31) / 32));
+    // enough workgroups that the tail of the last scheduling round is small against the total
+    // (4 workgroups/CU resident => 1024 slots); a strip costs (w-1) extra entering-row visits
+    static int target_wgs = 0;
+    if (!target_wgs) { const char* e = getenv("RTDM_FAST_WGS"); target_wgs = e ? atoi(e) : 8192; if (target_wgs < 1) target_wgs = 8192; }
+    int strips = (target_wgs + tiles * n - 1) / (tiles * n);
+    strips = max(1, min(strips, (nrows + 15) / 16));
     fg.rs = (nrows + strips - 1) / strips;
     strips = (nrows + fg.rs - 1) / fg.rs;
     const size_t ldsb = (size_t)(g.w + 2) * C::SLOT * 4;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_search_fast<D, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-    hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, cost, g, fg);
+    hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg);
 }
 
 bool fast_search_supported(const BMGeom& g)
@@ -326,7 +332,7 @@ bool fast_search_supported(const BMGeom& g)
     return false;
 }
 
-void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g, int n, hipStream_t stream)
+void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream)
 {
     const int np = fast_np(g);
     if (g.D == 64 && np == 3) launch_one<64, 3>(Lp, Rp, disp, cost, g, n, stream);

@@ -22,7 +22,7 @@ static constexpr int RS = 24;   // output rows per workgroup
 // TC = output columns per workgroup: 64 for whole frames, 8 for the narrow border strips that
 // the fast kernel leaves over (work per workgroup scales with TC + w - 1 sample columns).
 template <typename T, int TC>
-__global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, BMGeom g,
+__global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, T* cost, BMGeom g,
                                                         int gx0, int gx1)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
                 const int den = pp + nn - 2 * m1 + abs(pp - nn);
                 const int v = (D - mi - 1 + g.minD) * 256 + (den != 0 ? (pp - nn) * 256 / den : 0) + 15;
                 out = v >> 4;
-                if (g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = m1;
+                if (g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = (T)m1;
             }
             if (g.mask_cols && (col < g.vx0 || col >= g.vx1)) out = g.filtered;
             db[(size_t)y * disp.pitch_e + col] = (int16_t)out;
@@ -177,16 +177,16 @@ bool generic_search_supported(const BMGeom& g, bool* use16)
 }
 
 template <typename T, int TC>
-static void launch_generic_t(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g, int n,
+static void launch_generic_t(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n,
                              hipStream_t stream, int gx0, int gx1, size_t lds)
 {
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)k_search_generic<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
     dim3 grid((gx1 - gx0 + TC - 1) / TC, (g.vy1 - g.vy0 + RS - 1) / RS, n);
-    hipLaunchKernelGGL((k_search_generic<T, TC>), grid, dim3(256), lds, stream, Lp, Rp, disp, cost, g, gx0, gx1);
+    hipLaunchKernelGGL((k_search_generic<T, TC>), grid, dim3(256), lds, stream, Lp, Rp, disp, (T*)cost, g, gx0, gx1);
 }
 
-void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g,
+void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g,
                            int n, hipStream_t stream, int gx0, int gx1)
 {
     if (gx1 < 0) gx1 = g.width1;

@@ -34,7 +34,9 @@ struct rtdm_bm {
     uint8_t *dLp, *dRp;            // prefiltered planes   [maxB][maxH][ppitch]
     uint8_t *dInL, *dInR;          // staging for the host entry points
     int16_t* dOut;                 //                      [maxB][maxH][maxW]
-    int32_t *dCost, *dLabel, *dSize;
+    int32_t *dCost, *dLabel, *dSize, *dRowCnt;
+    uint32_t* dRuns;
+    int16_t* dHead;
     bool profiling;
     std::vector<StageEvent> pending;
     double stage_ms[RTDM_NUM_STAGES];
@@ -114,6 +116,7 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     if (max_width <= 0 || max_height <= 0 || max_batch <= 0 || max_width > 32767 || max_height > 32767)
         return RTDM_ERR_BAD_SIZE;
     if ((long)max_batch * max_width * max_height >= (1L << 31)) return RTDM_ERR_BAD_SIZE;
+    if (max_width > 4096) return RTDM_ERR_UNSUPPORTED;   // row kernels keep whole rows in LDS
     rc = use_device(device);
     if (rc) return rc;
     rtdm_bm* bm = new (std::nothrow) rtdm_bm();
@@ -134,6 +137,9 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dCost, px * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dLabel, px * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dSize, px * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dRuns, px * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dHead, px * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dRowCnt, (size_t)max_batch * max_height * sizeof(int32_t));
     if (e != hipSuccess) {
         g_hip_err = std::string("rtdm_bm_create: ") + hipGetErrorString(e);
         rtdm_bm_destroy(bm);
@@ -149,7 +155,7 @@ void rtdm_bm_destroy(rtdm_bm* bm)
     (void)hipSetDevice(bm->device);
     if (bm->stream) (void)hipStreamSynchronize(bm->stream);
     for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize};
+    void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (bm->stream) (void)hipStreamDestroy(bm->stream);
     delete bm;
@@ -184,6 +190,7 @@ static bool make_geom(const rtdm_bm* bm, int W, int H, BMGeom* g)
     g->width1 = W - g->rofs - g->D + 1;
     g->filtered = (g->minD - 1) * 16;
     g->want_cost = p.disp12MaxDiff >= 0;
+    g->cost16 = 2L * p.preFilterCap * p.blockSize * p.blockSize < 65536;
     g->mask_cols = p.disp12MaxDiff < 0;
     int r1[4] = {0, 0, W, H}, r2[4] = {0, 0, W, H};
     if (bm->roi1[2] > 0 && bm->roi1[3] > 0) std::copy(bm->roi1, bm->roi1 + 4, r1);
@@ -220,8 +227,12 @@ static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane
     const rtdm_bm_params& p = bm->p;
     BMGeom g;
     const bool any = make_geom(bm, W, H, &g);
-    launch_fill16(disp, W, H, n, g.filtered, s);
-    if (!any) return RTDM_OK;
+    if (!any) { launch_fill16(disp, 0, W, 0, H, n, g.filtered, s); return RTDM_OK; }
+    // the search kernels write columns [lofs, W) of the valid rows; everything else is FILTERED
+    launch_fill16(disp, 0, W, 0, g.vy0, n, g.filtered, s);
+    launch_fill16(disp, 0, W, g.vy1, H, n, g.filtered, s);
+    launch_fill16(disp, 0, g.lofs, g.vy0, g.vy1, n, g.filtered, s);
+    launch_fill16(disp, std::min(W, g.lofs + g.width1), W, g.vy0, g.vy1, n, g.filtered, s);
     StageEvent ev;
     const bool fast = fast_search_supported(g);
     bool u16 = false;
@@ -238,21 +249,30 @@ static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane
             int lx0, lx1, rx0, rx1;
             fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
             launch_search_fast(Lpr, Rpr, disp, bm->dCost, g, n, s);
-            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, lx0, lx1);
-            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, rx0, rx1);
+            if (border_search_supported(g)) {
+                launch_search_border(Lpr, Rpr, disp, bm->dCost, g, n, s, lx0, lx1, rx0, rx1);
+            } else {
+                launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, lx0, lx1);
+                launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, rx0, rx1);
+            }
         } else {
             launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s);
         }
         stage_end(bm, s, &ev);
     }
-    if (p.disp12MaxDiff >= 0) {
+    const bool speckle = p.speckleRange >= 0 && p.speckleWindowSize > 0;
+    const bool lr = p.disp12MaxDiff >= 0;
+    if (speckle) HIPC(hipMemsetAsync(bm->dRowCnt, 0, (size_t)n * H * sizeof(int32_t), s));
+    if (lr) {
         stage_begin(bm, RTDM_STAGE_LRCHECK, n, s, &ev);
-        launch_lrcheck(disp, bm->dCost, g, p.disp12MaxDiff, n, s);
+        if (speckle) launch_lrcheck(disp, bm->dCost, g, p.disp12MaxDiff, n, s, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead, p.speckleRange);
+        else         launch_lrcheck(disp, bm->dCost, g, p.disp12MaxDiff, n, s);
         stage_end(bm, s, &ev);
     }
-    if (p.speckleRange >= 0 && p.speckleWindowSize > 0) {
+    if (speckle) {
         stage_begin(bm, RTDM_STAGE_SPECKLE, n, s, &ev);
-        launch_speckle(disp, bm->dLabel, bm->dSize, W, H, n, g.filtered, p.speckleWindowSize, p.speckleRange, s);
+        launch_speckle(disp, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead, W, H, n, g.filtered, p.speckleWindowSize,
+                       p.speckleRange, lr, g.vy0, g.vy1, s);
         stage_end(bm, s, &ev);
     }
     HIPC(hipGetLastError());

@@ -18,6 +18,7 @@ struct BMGeom {
     int filtered;            // (minD-1)*16
     int mask_cols;           // 1: the search kernel masks columns outside [vx0,vx1) itself
     int want_cost;           // 1: a cost plane is written for the left-right check
+    int cost16;              // 1: the cost plane is uint16 (all SADs < 65536), else int32
 };
 
 struct Plane8 {  // batch of 8-bit images: frame f, row y at base + f*frame + y*pitch
@@ -30,32 +31,40 @@ struct Plane16W { int16_t* base; size_t pitch_e, frame_e; };  // strides in elem
 void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, int cap, int n,
                       hipStream_t stream);
 
-// Fill a batch of disparity frames with FILTERED.
-void launch_fill16(Plane16W disp, int W, int H, int n, int value, hipStream_t stream);
+// Fill the rectangle [x0,x1) x [y0,y1) of every disparity frame with `value`.
+void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int value, hipStream_t stream);
 
 // K2 (generic variant): any D <= 256, any odd w, LDS column sums; writes disp (+ int32 cost).
 // Returns false if the configuration does not fit (caller reports RTDM_ERR_UNSUPPORTED).
 bool generic_search_supported(const BMGeom& g, bool* use16);
 // [gx0, gx1) restricts the output-column range (gx1 < 0: all of [0, width1)).
-void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g,
+void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g,
                            int n, hipStream_t stream, int gx0 = 0, int gx1 = -1);
 
 // K2 (fast variant): packed-u8 quad-SAD kernel for the common configurations.  Works on the
 // prefiltered planes and covers the output columns whose window needs no border clamping; the
 // remaining border columns [lx0,lx1) and [rx0,rx1) go to the generic kernel.
 bool fast_search_supported(const BMGeom& g);
-void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, int32_t* cost, const BMGeom& g,
+void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g,
                         int n, hipStream_t stream);
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
+// wave-per-column kernel for those border columns (falls back to the generic kernel if unsupported)
+bool border_search_supported(const BMGeom& g);
+void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n,
+                          hipStream_t stream, int lx0, int lx1, int rx0, int rx1);
 
-// K3: row-local left-right consistency check (+ column masking to the valid rectangle).
-void launch_lrcheck(Plane16W disp, const int32_t* cost, const BMGeom& g, int disp12MaxDiff, int n,
-                    hipStream_t stream);
+// K3: row-local left-right consistency check (+ column masking to the valid rectangle).  With
+// label != nullptr the speckle filter's per-row init runs on the checked row in the same pass.
+void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
+                    hipStream_t stream, int32_t* label = nullptr, int32_t* size = nullptr,
+                    uint32_t* runs = nullptr, int32_t* rowcnt = nullptr, int16_t* headmap = nullptr, int spkDiff = 0);
 
 // K4: speckle filter (connected components under |a-b| <= maxDiff, size <= maxSize removed).
-// label/size: n*W*H int32 each.
-void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, int W, int H, int n, int newVal,
-                    int maxSize, int maxDiff, hipStream_t stream);
+// label/size/runs/headmap: n*W*H elements each, rowcnt: n*H.  init_done: rows [y_lo,y_hi) were
+// initialised by launch_lrcheck (rowcnt zeroed beforehand) and every other row is entirely `newVal`.
+void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
+                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int y_lo, int y_hi,
+                    hipStream_t stream);
 
 // K5: erode / dilate / dilate / erode with the 10x10 ellipse; tmp = n*W*H bytes scratch.
 void launch_morph_open_close(Plane8 in, Plane8W out, uint8_t* tmp0, uint8_t* tmp1, int W, int H,
