@@ -338,6 +338,10 @@ __global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label,
 
 // merge: one thread = 8 consecutive pixels of a row pair (y, y+1); no LDS, no scans: the heads come
 // from the head map.  A pixel is skipped when its left neighbour already linked the same two runs.
+// VEC: rows are 16-byte aligned, so the 8 pixels of each row come in as one 128-bit load.
+struct alignas(16) Short8 { int16_t v[8]; };
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int H,
                                                    int y_lo, int y_hi, int newVal, int maxDiff)
 {
@@ -351,21 +355,33 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
     const int base0 = (f * H + y) * W, base1 = base0 + W;
     const int16_t* h0 = headmap + base0;
     const int16_t* h1 = headmap + base1;
-    int pa = newVal, pb = newVal, ph0 = -1, ph1 = -1;       // left neighbour state
+    Short8 a8, b8, ha8, hb8;
+    const bool full = VEC && x0 + 8 <= W;
+    if (full) {
+        a8 = *(const Short8*)(d0 + x0); b8 = *(const Short8*)(d1 + x0);
+    } else {
+        for (int k = 0; k < 8; ++k) { const int x = min(x0 + k, W - 1); a8.v[k] = d0[x]; b8.v[k] = d1[x]; }
+    }
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) any |= conn(a8.v[k], b8.v[k], newVal, maxDiff);
+    if (!any) return;
+    if (full) {
+        ha8 = *(const Short8*)(h0 + x0); hb8 = *(const Short8*)(h1 + x0);
+    } else {
+        for (int k = 0; k < 8; ++k) { const int x = min(x0 + k, W - 1); ha8.v[k] = h0[x]; hb8.v[k] = h1[x]; }
+    }
     bool pc = false;
+    int ph0 = -1, ph1 = -1;                                   // left neighbour state
     if (x0 > 0) {
-        pa = d0[x0 - 1]; pb = d1[x0 - 1];
-        pc = conn(pa, pb, newVal, maxDiff);
+        pc = conn(d0[x0 - 1], d1[x0 - 1], newVal, maxDiff);
         if (pc) { ph0 = h0[x0 - 1]; ph1 = h1[x0 - 1]; }
     }
-    for (int x = x0; x < min(x0 + 8, W); ++x) {
-        const int a = d0[x], b = d1[x];
-        const bool c = conn(a, b, newVal, maxDiff);
-        int ha = -1, hb = -1;
-        if (c) {
-            ha = h0[x]; hb = h1[x];
-            if (!(pc && ph0 == ha && ph1 == hb)) uf_union(label, base0 + ha, base1 + hb);
-        }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const bool c = (x0 + k < W) && conn(a8.v[k], b8.v[k], newVal, maxDiff);
+        const int ha = ha8.v[k], hb = hb8.v[k];
+        if (c && !(pc && ph0 == ha && ph1 == hb)) uf_union(label, base0 + ha, base1 + hb);
         pc = c; ph0 = ha; ph1 = hb;
     }
 }
@@ -422,8 +438,10 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
     const int pairs_hi = min(y_hi, H) - 1;           // pairs (y, y+1) with both rows initialised
     if (pairs_hi > y_lo) {
         const int nxb = (W + 7) / 8;
-        hipLaunchKernelGGL(k_spk_merge, dim3((nxb * (pairs_hi - y_lo) + 255) / 256, n), block, 0, stream, disp, label, headmap,
-                           W, H, y_lo, pairs_hi, newVal, maxDiff);
+        const bool vec = (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2)) & 15) == 0 && (W & 7) == 0;
+        dim3 grid((nxb * (pairs_hi - y_lo) + 255) / 256, n);
+        if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, H, y_lo, pairs_hi, newVal, maxDiff);
+        else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, H, y_lo, pairs_hi, newVal, maxDiff);
     }
     const int nrows = n * H;
     hipLaunchKernelGGL(k_spk_count, dim3((nrows + 3) / 4), block, 0, stream, label, size, runs, rowcnt, W, nrows, maxSize);

@@ -50,40 +50,44 @@ struct FastCfg {
     static constexpr int ITEMS = (SLOT + 255) / 256;
 };
 
-// Horizontal SADs of one staged row for this lane's column: acc[g] += the 4 packed SADs of
-// disparity group g; tacc += sum |L - cap| over the window row.
-template <int D, int NP>
-__device__ __forceinline__ void row_sads(const uint32_t* __restrict__ lp, const uint32_t* __restrict__ rp,
-                                         uint32_t lastmask, uint32_t capb, uint64_t (&acc)[D / 4], uint32_t& tacc)
+// Horizontal SADs of one staged row for this lane's column, disparity groups [G0, G0+GN):
+// acc[g - G0] += the 4 packed SADs of group g.  l[] = the NP window pieces of the left row.
+template <int D, int NP, int G0, int GN>
+__device__ __forceinline__ void row_sads(const uint32_t (&l)[NP], const uint32_t* __restrict__ rp, uint64_t (&acc)[GN])
 {
-    using C = FastCfg<D, NP>;
-    uint32_t l[NP];
+    // gfx950 wants 64-bit operands in even-aligned VGPR pairs.  Windows at odd dword offsets are
+    // loaded through a second pointer whose index is laundered, so that the compiler issues its own
+    // ds_read2_b32 for them instead of rebuilding the pair from already-loaded dwords with v_mov
+    // (the laundered value is the INDEX, so the pointer keeps its LDS address space).
+    int one = 1;
+    asm volatile("" : "+v"(one));
+    const uint32_t* rpo = rp + one;
+#pragma unroll
+    for (int j = G0; j < G0 + GN + NP - 1; ++j) {
+        const uint32_t* wp = (j & 1) ? rpo + (j - 1) : rp + j;
+        const uint64_t win = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int gi = j - k - G0;
+            if (gi >= 0 && gi < GN) {
+                if (k == NP - 1) acc[gi] = __builtin_amdgcn_mqsad_pk_u16_u8(win, l[k], acc[gi]);
+                else             acc[gi] = __builtin_amdgcn_qsad_pk_u16_u8(win, l[k], acc[gi]);
+            }
+        }
+    }
+}
+
+// The NP window pieces of the left row (last one masked) and their texture sum |L - cap|.
+template <int NP>
+__device__ __forceinline__ void left_pieces(const uint32_t* __restrict__ lp, uint32_t lastmask, uint32_t capb,
+                                            uint32_t (&l)[NP], uint32_t& tacc)
+{
 #pragma unroll
     for (int k = 0; k < NP; ++k) l[k] = lp[k];
     l[NP - 1] &= lastmask;
 #pragma unroll
     for (int k = 0; k < NP - 1; ++k) tacc = __builtin_amdgcn_sad_u8(l[k], capb, tacc);
     tacc = __builtin_amdgcn_msad_u8(capb, l[NP - 1], tacc);   // zero bytes of the reference are skipped
-    // gfx950 wants 64-bit operands in even-aligned VGPR pairs.  Windows at odd dword offsets are
-    // loaded through a second, laundered pointer so that the compiler issues its own ds_read2_b32
-    // for them instead of rebuilding the pair from already-loaded dwords with v_mov.
-    // (the laundered value is the INDEX, so the pointer keeps its LDS address space)
-    int one = 1;
-    asm volatile("" : "+v"(one));
-    const uint32_t* rpo = rp + one;
-#pragma unroll
-    for (int j = 0; j < C::NW; ++j) {
-        const uint32_t* wp = (j & 1) ? rpo + (j - 1) : rp + j;
-        const uint64_t win = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int gi = j - k;
-            if (gi >= 0 && gi < C::NG) {
-                if (k == NP - 1) acc[gi] = __builtin_amdgcn_mqsad_pk_u16_u8(win, l[k], acc[gi]);
-                else             acc[gi] = __builtin_amdgcn_qsad_pk_u16_u8(win, l[k], acc[gi]);
-            }
-        }
-    }
 }
 
 __device__ __forceinline__ int div_trunc_small(int num, int den)   // den > 0, |num| < 2^24
@@ -176,23 +180,37 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
         if (more) issue(row_in + 1);
 
         {   // entering row: accumulate straight into the running sums
-            const uint32_t* lp = lds + slot_in * SLOT + phi * LWD + lane;
-            const uint32_t* rp = lds + slot_in * SLOT + 4 * LWD + phi * RWD + lane;
-            row_sads<D, NP>(lp, rp, fg.lastmask, capb, S, tsum);
+            // (the index is laundered so that the compiler keeps ONE base register per copy and
+            //  folds the window offsets into the ds_read immediates instead of one v_add per read)
+            int li = slot_in * SLOT + phi * LWD + lane, ri = slot_in * SLOT + 4 * LWD + phi * RWD + lane;
+            asm volatile("" : "+v"(li), "+v"(ri));
+            uint32_t l[NP];
+            left_pieces<NP>(lds + li, fg.lastmask, capb, l, tsum);
+            row_sads<D, NP, 0, NG>(l, lds + ri, S);
         }
         if (s >= w) {   // leaving row: recompute and subtract
-            const uint32_t* lp = lds + slot_out * SLOT + phi * LWD + lane;
-            const uint32_t* rp = lds + slot_out * SLOT + 4 * LWD + phi * RWD + lane;
-            uint64_t T[NG];
-#pragma unroll
-            for (int i = 0; i < NG; ++i) T[i] = 0;
+            int li = slot_out * SLOT + phi * LWD + lane, ri = slot_out * SLOT + 4 * LWD + phi * RWD + lane;
+            asm volatile("" : "+v"(li), "+v"(ri));
+            uint32_t l[NP];
             uint32_t told = 0;
-            row_sads<D, NP>(lp, rp, fg.lastmask, capb, T, told);
+            left_pieces<NP>(lds + li, fg.lastmask, capb, l, told);
+            // in chunks of 16 disparity groups, so that the temporaries stay at 32 VGPRs for any D
+            constexpr int CG = NG < 16 ? NG : 16;
 #pragma unroll
-            for (int i = 0; i < NG; ++i) {
-                const uint32_t lo = pk_sub((uint32_t)S[i], (uint32_t)T[i]);
-                const uint32_t hi = pk_sub((uint32_t)(S[i] >> 32), (uint32_t)(T[i] >> 32));
-                S[i] = (uint64_t)lo | ((uint64_t)hi << 32);
+            for (int c0 = 0; c0 < NG; c0 += CG) {
+                uint64_t T[CG];
+#pragma unroll
+                for (int i = 0; i < CG; ++i) T[i] = 0;
+                if (c0 == 0)       row_sads<D, NP, 0, CG>(l, lds + ri, T);
+                else if (c0 == 16) row_sads<D, NP, (NG > 16 ? 16 : 0), CG>(l, lds + ri, T);
+                else if (c0 == 32) row_sads<D, NP, (NG > 32 ? 32 : 0), CG>(l, lds + ri, T);
+                else               row_sads<D, NP, (NG > 48 ? 48 : 0), CG>(l, lds + ri, T);
+#pragma unroll
+                for (int i = 0; i < CG; ++i) {
+                    const uint32_t lo = pk_sub((uint32_t)S[c0 + i], (uint32_t)T[i]);
+                    const uint32_t hi = pk_sub((uint32_t)(S[c0 + i] >> 32), (uint32_t)(T[i] >> 32));
+                    S[c0 + i] = (uint64_t)lo | ((uint64_t)hi << 32);
+                }
             }
             tsum -= told;
             slot_out = (slot_out + 1 == RING) ? 0 : slot_out + 1;
@@ -204,14 +222,15 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
 #pragma unroll
             for (int i = 0; i < NG; ++i) { rr[2 * i] = (uint32_t)S[i]; rr[2 * i + 1] = (uint32_t)(S[i] >> 32); }
             // (minsad, first argmin) via 32-bit keys sad << 8 | e
-            uint32_t kmin = 0xffffffffu;
+            uint32_t kacc[2] = {0xffffffffu, 0xffffffffu};   // two chains: no back-to-back dependency
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 const uint32_t ec = (uint32_t)(2 * i) | ((uint32_t)(2 * i + 1) << 8);
                 const uint32_t klo = __builtin_amdgcn_perm(rr[i], ec, 0x0C050400u);
                 const uint32_t khi = __builtin_amdgcn_perm(rr[i], ec, 0x0C070601u);
-                kmin = min(min(kmin, klo), khi);
+                kacc[i & 1] = min(min(kacc[i & 1], klo), khi);
             }
+            const uint32_t kmin = min(kacc[0], kacc[1]);
             const int m1 = (int)(kmin >> 8);
             const int a = (int)(kmin & 0xffu);
             // fetch the two packed registers that hold sad[a-1 .. a+1]
@@ -250,9 +269,19 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
                 uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
                 T = min(T, 32766u);
                 const uint32_t T1 = T + 1u, T1pk = T1 * 0x00010001u;
-                uint32_t z = 0;
+                // saturating sums of non-negative terms are order independent: four chains
+                // (the empty asm pins "four subtractions, then four additions": back-to-back dependent
+                //  packed ops cost a wait state each on gfx950)
+                uint32_t zz[4] = {0, 0, 0, 0};
 #pragma unroll
-                for (int i = 0; i < NR; ++i) z = pk_add_sat(z, pk_sub_sat(T1pk, rr[i]));
+                for (int i = 0; i < NR; i += 4) {
+                    uint32_t t0 = pk_sub_sat(T1pk, rr[i]), t1 = pk_sub_sat(T1pk, rr[i + 1]);
+                    uint32_t t2 = pk_sub_sat(T1pk, rr[i + 2]), t3 = pk_sub_sat(T1pk, rr[i + 3]);
+                    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+                    zz[0] = pk_add_sat(zz[0], t0); zz[1] = pk_add_sat(zz[1], t1);
+                    zz[2] = pk_add_sat(zz[2], t2); zz[3] = pk_add_sat(zz[3], t3);
+                }
+                const uint32_t z = pk_add_sat(pk_add_sat(zz[0], zz[1]), pk_add_sat(zz[2], zz[3]));
                 const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
                 const uint32_t wsame = term(m1);
                 const uint32_t wother = (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
@@ -289,6 +318,7 @@ static bool fast_range(const BMGeom& g, int* x0, int* nx)
     int xl = 0, xh = g.width1 - 1;
     xl = max(xl, r - g.lofs); xl = max(xl, r - g.rofs);
     xh = min(xh, g.W - 1 - g.lofs - r); xh = min(xh, g.W - g.D - g.rofs - r);
+    xl = max(xl, g.cx0 - g.lofs); xh = min(xh, g.cx1 - g.lofs - 1);      // setROI1: only the needed columns
     if (x0) *x0 = xl;
     if (nx) *nx = xh - xl + 1;
     return xh >= xl;
@@ -345,7 +375,7 @@ void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1)
 {
     int x0 = 0, nx = 0;
     fast_range(g, &x0, &nx);
-    *lx0 = 0; *lx1 = x0; *rx0 = x0 + nx; *rx1 = g.width1;
+    *lx0 = max(0, g.cx0 - g.lofs); *lx1 = x0; *rx0 = x0 + nx; *rx1 = min(g.width1, g.cx1 - g.lofs);
 }
 
 }  // namespace rtdm

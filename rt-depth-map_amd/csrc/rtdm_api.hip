@@ -203,6 +203,13 @@ static bool make_geom(const rtdm_bm* bm, int W, int H, BMGeom* g)
     xmin = std::max(xmin, 0); xmax = std::min(xmax, W);
     ymin = std::max(ymin, g->r); ymax = std::min(ymax, H - g->r);
     g->vx0 = xmin; g->vx1 = xmax; g->vy0 = ymin; g->vy1 = ymax;
+    // Columns worth searching (estimator.cpp:54 shrinks the rectangle every frame with setROI1):
+    // validateDisparity lets column x vote for x - round(d/16) in [x - maxD - 1, x - minD + 1] and
+    // reads the votes of x - floor/ceil(d/16), so a valid column depends on searched columns at
+    // most D + |minD| + 2 away.  Everything else is masked to FILTERED anyway.
+    const int reach = (p.disp12MaxDiff >= 0) ? g->D + std::abs(g->minD) + 2 : 0;
+    g->cx0 = std::max(g->lofs, xmin - reach);
+    g->cx1 = std::min(std::min(W, g->lofs + g->width1), xmax + reach);
     if (g->lofs >= W || g->rofs >= W || g->width1 < 1) return false;
     return xmax > xmin && ymax > ymin;
 }
@@ -228,11 +235,11 @@ static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane
     BMGeom g;
     const bool any = make_geom(bm, W, H, &g);
     if (!any) { launch_fill16(disp, 0, W, 0, H, n, g.filtered, s); return RTDM_OK; }
-    // the search kernels write columns [lofs, W) of the valid rows; everything else is FILTERED
+    // the search kernels write columns [cx0, cx1) of the valid rows; everything else is FILTERED
     launch_fill16(disp, 0, W, 0, g.vy0, n, g.filtered, s);
     launch_fill16(disp, 0, W, g.vy1, H, n, g.filtered, s);
-    launch_fill16(disp, 0, g.lofs, g.vy0, g.vy1, n, g.filtered, s);
-    launch_fill16(disp, std::min(W, g.lofs + g.width1), W, g.vy0, g.vy1, n, g.filtered, s);
+    launch_fill16(disp, 0, g.cx0, g.vy0, g.vy1, n, g.filtered, s);
+    launch_fill16(disp, g.cx1, W, g.vy0, g.vy1, n, g.filtered, s);
     StageEvent ev;
     const bool fast = fast_search_supported(g);
     bool u16 = false;
@@ -256,7 +263,7 @@ static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane
                 launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, rx0, rx1);
             }
         } else {
-            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s);
+            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, g.cx0 - g.lofs, g.cx1 - g.lofs);
         }
         stage_end(bm, s, &ev);
     }

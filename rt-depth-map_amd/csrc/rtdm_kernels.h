@@ -15,6 +15,8 @@ struct BMGeom {
     int cap, tex, uniq;  // preFilterCap, textureThreshold, uniquenessRatio
     int lofs, rofs, width1;
     int vx0, vx1, vy0, vy1;  // valid-disparity rectangle [vx0,vx1) x [vy0,vy1)
+    int cx0, cx1;            // image columns that have to be searched: the valid columns plus, when the
+                             // left-right check is on, every column that can vote for them (setROI1 skips the rest)
     int filtered;            // (minD-1)*16
     int mask_cols;           // 1: the search kernel masks columns outside [vx0,vx1) itself
     int want_cost;           // 1: a cost plane is written for the left-right check

@@ -108,6 +108,17 @@ def test_config1_320x240_d32_w7_and_roi_crop(pkg, oracle, synth):
     assert_same(*both(pkg, oracle, lv, rv, numDisparities=32, blockSize=7, roi1=roi))
 
 
+@pytest.mark.parametrize("roi", [(200, 100, 180, 150), (70, 10, 560, 460), (0, 0, 300, 200), (500, 300, 140, 180),
+                                 (66, 4, 10, 12), (320, 200, 64, 64)])
+def test_roi_column_skipping_is_exact_on_fast_path(pkg, oracle, synth, roi):
+    # estimator.cpp:54: the caller shrinks ROI1 to the union of the object boxes before every compute;
+    # the search then only covers the columns that can influence the valid rectangle
+    L, R = synth.make_pair(synth.STREAM_SEED + 31, 640, 480, 64)
+    for md in (1, -1):
+        assert_same(*both(pkg, oracle, L, R, numDisparities=64, blockSize=9, roi1=roi, disp12MaxDiff=md))
+    assert_same(*both(pkg, oracle, L, R, numDisparities=64, blockSize=9, roi1=roi, roi2=(40, 20, 560, 400)))
+
+
 def test_config2_640x480_d64_w9(pkg, oracle, synth):
     L, R = synth.make_pair(synth.STREAM_SEED + 1, 640, 480, 64)
     got, want = both(pkg, oracle, L, R, numDisparities=64, blockSize=9)
