@@ -122,6 +122,15 @@ def main():
     avg_ms = srch["total_ms"] / max(1, srch["launches"])
     frames_per_launch = srch["frames"] / max(1, srch["launches"])
     achieved = ALGO_BYTES_PER_PAIR * frames_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM bytes of the dominant kernel from the rocprofv3 PMC passes (tools/pmc_traffic.sh; FETCH_SIZE x2 +
+    # WRITE_SIZE, per the gfx950 correction); collected offline because --pmc cannot run inside this process
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        if m.search_variant == "fast_qsad":
+            traffic = int(pm["kernels"]["k_search_fast<64,3>"]["hbm_bytes_per_pair"] * frames_per_launch)
+    except Exception:
+        traffic = None
     out = {
         "metric": "stereo-pairs/sec, 1280x720 d=64 9x9 SAD", "value": round(value, 1), "unit": "stereo-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -134,7 +143,8 @@ def main():
                    "valid_fraction": round(valid_frac, 4)},
         "roofline": {"bound": "hbm", "kernel": "SAD search (%s)" % m.search_variant,
                      "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "traffic_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_pmc_traffic.json",
                      "avg_launch_ms": round(avg_ms, 4), "pairs_per_launch": frames_per_launch,
                      "algorithmic_bytes_per_pair": ALGO_BYTES_PER_PAIR},
         "stage_ms_per_launch": {k: round(v["total_ms"] / max(1, v["launches"]), 4) for k, v in stages.items()},

@@ -6,6 +6,7 @@
 #include "rtdm_kernels.h"
 
 #include <algorithm>
+#include <cstring>
 #include <new>
 #include <string>
 #include <vector>
@@ -37,6 +38,8 @@ struct rtdm_bm {
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
     int16_t* dHead;
+    uint8_t* hStage;               // page-locked staging for the single-frame host entry point
+    size_t hStageBytes;
     bool profiling;
     std::vector<StageEvent> pending;
     double stage_ms[RTDM_NUM_STAGES];
@@ -139,6 +142,8 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dSize, px * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dRuns, px * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dHead, px * sizeof(int16_t));
+    bm->hStageBytes = 2 * bm->ppitch * (size_t)max_height + (size_t)max_width * max_height * sizeof(int16_t);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&bm->hStage, bm->hStageBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dRowCnt, (size_t)max_batch * max_height * sizeof(int32_t));
     if (e != hipSuccess) {
         g_hip_err = std::string("rtdm_bm_create: ") + hipGetErrorString(e);
@@ -157,6 +162,7 @@ void rtdm_bm_destroy(rtdm_bm* bm)
     for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (bm->hStage) (void)hipHostFree(bm->hStage);
     if (bm->stream) (void)hipStreamDestroy(bm->stream);
     delete bm;
 }
@@ -360,15 +366,25 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
     HIPC(hipSetDevice(bm->device));
     hipStream_t s = bm->stream;
     const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
-    HIPC(hipMemcpy2DAsync(bm->dInL, dpitch, left, left_pitch, width, height, hipMemcpyHostToDevice, s));
-    HIPC(hipMemcpy2DAsync(bm->dInR, dpitch, right, right_pitch, width, height, hipMemcpyHostToDevice, s));
+    // The caller's Mats are pageable ROI views (estimator.cpp:33,36): gather the rows into the
+    // page-locked staging area on the host, then ONE linear async copy per direction.
+    uint8_t* hL = bm->hStage;
+    uint8_t* hR = hL + dframe;
+    int16_t* hD = (int16_t*)(bm->hStage + 2 * bm->ppitch * (size_t)bm->maxH);
+    for (int y = 0; y < height; ++y) {
+        memcpy(hL + (size_t)y * dpitch, left + (size_t)y * left_pitch, (size_t)width);
+        memcpy(hR + (size_t)y * dpitch, right + (size_t)y * right_pitch, (size_t)width);
+    }
+    HIPC(hipMemcpyAsync(bm->dInL, hL, dframe, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(bm->dInR, hR, dframe, hipMemcpyHostToDevice, s));
     Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
     Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
     rc = run_chunk(bm, 1, L, R, width, height, O, s);
     if (rc) return rc;
-    HIPC(hipMemcpy2DAsync(disp, disp_pitch, bm->dOut, (size_t)width * 2, (size_t)width * 2, height,
-                          hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(hD, bm->dOut, (size_t)width * height * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    for (int y = 0; y < height; ++y)
+        memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * width, (size_t)width * sizeof(int16_t));
     return RTDM_OK;
 }
 
