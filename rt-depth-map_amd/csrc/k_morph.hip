@@ -3,69 +3,98 @@
 // /root/reference/include/filter/mf-sw.h:11-12).  Semantics: SURVEY.md Appendix B; oracle:
 // oracle/morph_oracle.c.
 //
-// One workgroup produces a 64x32 output tile of ONE pass (erode or dilate); the source tile with
-// its halo (5 up/left, 4 down/right) is staged in LDS, then each output is the min/max over the
-// ten element rows, each row a contiguous run [j1, j2] of the staged tile.  Out-of-image samples
-// are staged as the neutral value (255 for erode, 0 for dilate), which is OpenCV's constant
-// border that never wins.
+// ONE launch for all four passes (erode, dilate, dilate, erode).  A workgroup owns a 64x32 output
+// tile; the source tile with a (20 up/left, 16 down/right) halo is staged in LDS once and each
+// pass shrinks the live region by the element's reach (5 up/left, 4 down/right), so nothing but
+// the input and the final output touches HBM (algorithmic bytes: 1 read + 1 write per pixel).
+// The element's ten rows are runs of length 1, 7, 9, 10 x5, 9, 7 (Appendix B), so each pass first
+// builds horizontal running minima (maxima) of length 7, 9 and 10 per row, then combines ten values
+// vertically: ~20 LDS accesses per pixel and pass instead of 84.
+// Out-of-image samples never win: they are staged as the neutral value of the pass that reads them
+// (255 before an erosion, 0 before a dilation), which is OpenCV's default constant border.
 #include "rtdm_kernels.h"
 
 namespace rtdm {
 
-static constexpr int MT_W = 64, MT_H = 32;     // output tile
-static constexpr int MH_L = 5, MH_R = 4;       // halo (anchor = (5,5) of a 10x10 element)
-static constexpr int MS_W = MT_W + MH_L + MH_R + 3;  // 76: staged row stride (multiple of 4)
-static constexpr int MS_H = MT_H + MH_L + MH_R;      // 41
+static constexpr int TW = 64, TH = 32;          // output tile
+static constexpr int RL = 5, RR = 4;            // reach of one pass: left/up, right/down
+static constexpr int SW = TW + 4 * (RL + RR);   // 100 staged columns
+static constexpr int SH = TH + 4 * (RL + RR);   // 68 staged rows
+static constexpr int SP = 104;                  // row pitch of the LDS planes
 
-// element rows of getStructuringElement(MORPH_ELLIPSE, Size(10,10)) -- SURVEY.md Appendix B
-__constant__ int c_j1[10] = {5, 2, 1, 0, 0, 0, 0, 0, 1, 2};
-__constant__ int c_j2[10] = {5, 8, 9, 9, 9, 9, 9, 9, 9, 8};
+template <bool DILATE> __device__ __forceinline__ int mm(int a, int b) { return DILATE ? max(a, b) : min(a, b); }
 
+// One pass over the live region: input plane `in` valid on columns [c0, c0+cw) x rows [r0, r0+rh)
+// (tile-local coordinates), output written to `out` on the region shrunk by the reach.
 template <bool DILATE>
-__global__ __launch_bounds__(256) void k_morph_pass(Plane8 in, Plane8W out, int W, int H)
+__device__ __forceinline__ void morph_pass(const uint8_t* in, uint8_t* out, uint8_t* h7, uint8_t* h9, uint8_t* h10,
+                                           int c0, int r0, int cw, int rh, int gx0, int gy0, int W, int H, int next_neutral)
 {
-    __shared__ uint8_t tile[MS_H * MS_W];
-    const int f = blockIdx.z;
-    const int tx0 = blockIdx.x * MT_W, ty0 = blockIdx.y * MT_H;
-    const uint8_t* src = in.base + (size_t)f * in.frame;
-    const uint8_t neutral = DILATE ? 0 : 255;
-    for (int i = threadIdx.x; i < MS_H * MS_W; i += 256) {
-        const int sy = i / MS_W, sx = i - sy * MS_W;
-        const int y = ty0 + sy - MH_L, x = tx0 + sx - MH_L;
-        uint8_t v = neutral;
-        if (sx < MT_W + MH_L + MH_R && x >= 0 && x < W && y >= 0 && y < H) v = src[(size_t)y * in.pitch + x];
-        tile[i] = v;
+    // horizontal running extrema; h7[x] covers [x, x+7), h9 [x, x+9), h10 [x, x+10); each is produced
+    // for every x whose span stays inside the live columns [c0, c0+cw)
+    const int hw = cw - 6;
+    for (int i = threadIdx.x; i < rh * hw; i += 256) {
+        const int y = r0 + i / hw, xr = i % hw, x = c0 + xr;
+        const uint8_t* p = in + y * SP + x;
+        int m = p[0];
+#pragma unroll
+        for (int k = 1; k < 7; ++k) m = mm<DILATE>(m, p[k]);
+        h7[y * SP + x] = (uint8_t)m;
+        if (xr + 9 <= cw) {
+            m = mm<DILATE>(m, mm<DILATE>(p[7], p[8]));
+            h9[y * SP + x] = (uint8_t)m;
+            if (xr + 10 <= cw) h10[y * SP + x] = (uint8_t)mm<DILATE>(m, p[9]);
+        }
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63;
-    const int x = tx0 + lx;
-    uint8_t* dst = out.base + (size_t)f * out.frame;
-    for (int ly = threadIdx.x >> 6; ly < MT_H; ly += 4) {
-        const int y = ty0 + ly;
-        int acc = neutral;
+    // output (y, x) for x in [c0+5, c0+cw-4), y in [r0+5, r0+rh-4):  element row i reads source row
+    // y+i-5, columns x+j-5 for j in its run (Appendix B): 5 | 2..8 | 1..9 | 0..9 x5 | 1..9 | 2..8
+    const int ow = cw - (RL + RR), oh = rh - (RL + RR);
+    for (int i = threadIdx.x; i < ow * oh; i += 256) {
+        const int y = r0 + RL + i / ow, x = c0 + RL + i % ow;
+        int m = in[(y - 5) * SP + x];
+        m = mm<DILATE>(m, h7[(y - 4) * SP + x - 3]);
+        m = mm<DILATE>(m, h9[(y - 3) * SP + x - 4]);
 #pragma unroll
-        for (int i = 0; i < 10; ++i) {
-            const uint8_t* rowp = tile + (ly + i) * MS_W + lx;    // src(y + i - 5, x + j - 5)
-            for (int j = c_j1[i]; j <= c_j2[i]; ++j) {
-                const int v = rowp[j];
-                acc = DILATE ? max(acc, v) : min(acc, v);
-            }
-        }
-        if (x < W && y < H) dst[(size_t)y * out.pitch + x] = (uint8_t)acc;
+        for (int k = -2; k <= 2; ++k) m = mm<DILATE>(m, h10[(y + k) * SP + x - 5]);
+        m = mm<DILATE>(m, h9[(y + 3) * SP + x - 4]);
+        m = mm<DILATE>(m, h7[(y + 4) * SP + x - 3]);
+        const int gx = gx0 + x, gy = gy0 + y;
+        if (gx < 0 || gx >= W || gy < 0 || gy >= H) m = next_neutral;   // outside the image: never wins next pass
+        out[y * SP + x] = (uint8_t)m;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_morph_open_close(Plane8 in, Plane8W out, int W, int H)
+{
+    __shared__ uint8_t A[SH * SP], B[SH * SP], h7[SH * SP], h9[SH * SP], h10[SH * SP];
+    const int f = blockIdx.z;
+    const int gx0 = blockIdx.x * TW - 4 * RL, gy0 = blockIdx.y * TH - 4 * RL;   // image coords of tile-local (0,0)
+    const uint8_t* src = in.base + (size_t)f * in.frame;
+    for (int i = threadIdx.x; i < SH * SW; i += 256) {
+        const int y = i / SW, x = i - y * SW;
+        const int gx = gx0 + x, gy = gy0 + y;
+        A[y * SP + x] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? src[(size_t)gy * in.pitch + gx] : (uint8_t)255;
+    }
+    __syncthreads();
+    const int S = RL + RR;
+    morph_pass<false>(A, B, h7, h9, h10, 0, 0, SW, SH, gx0, gy0, W, H, 0);                               // erode  -> dilate next
+    morph_pass<true>(B, A, h7, h9, h10, RL, RL, SW - S, SH - S, gx0, gy0, W, H, 0);                      // dilate -> dilate next
+    morph_pass<true>(A, B, h7, h9, h10, 2 * RL, 2 * RL, SW - 2 * S, SH - 2 * S, gx0, gy0, W, H, 255);    // dilate -> erode next
+    morph_pass<false>(B, A, h7, h9, h10, 3 * RL, 3 * RL, SW - 3 * S, SH - 3 * S, gx0, gy0, W, H, 0);     // erode  -> final
+    uint8_t* dst = out.base + (size_t)f * out.frame;
+    for (int i = threadIdx.x; i < TW * TH; i += 256) {
+        const int y = i / TW, x = i - y * TW;
+        const int gx = blockIdx.x * TW + x, gy = blockIdx.y * TH + y;
+        if (gx < W && gy < H) dst[(size_t)gy * out.pitch + gx] = A[(y + 4 * RL) * SP + x + 4 * RL];
     }
 }
 
-void launch_morph_open_close(Plane8 in, Plane8W out, uint8_t* tmp0, uint8_t* tmp1, int W, int H,
-                             int n, hipStream_t stream)
+void launch_morph_open_close(Plane8 in, Plane8W out, uint8_t*, uint8_t*, int W, int H, int n, hipStream_t stream)
 {
-    dim3 grid((W + MT_W - 1) / MT_W, (H + MT_H - 1) / MT_H, n), block(256);
-    const size_t tp = (size_t)W, tf = (size_t)W * H;
-    Plane8W t0w{tmp0, tp, tf}, t1w{tmp1, tp, tf};
-    Plane8 t0r{tmp0, tp, tf}, t1r{tmp1, tp, tf};
-    hipLaunchKernelGGL(k_morph_pass<false>, grid, block, 0, stream, in, t0w, W, H);    // erode
-    hipLaunchKernelGGL(k_morph_pass<true>, grid, block, 0, stream, t0r, t1w, W, H);    // dilate
-    hipLaunchKernelGGL(k_morph_pass<true>, grid, block, 0, stream, t1r, t0w, W, H);    // dilate
-    hipLaunchKernelGGL(k_morph_pass<false>, grid, block, 0, stream, t0r, out, W, H);   // erode
+    dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, n);
+    hipLaunchKernelGGL(k_morph_open_close, grid, dim3(256), 0, stream, in, out, W, H);
 }
 
 }  // namespace rtdm

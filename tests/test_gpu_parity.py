@@ -233,3 +233,19 @@ def test_device_synth_is_bit_identical_to_numpy(pkg, synth, W, H, D):
     pkg.synth_pairs_device(dL, dR, first_frame=5, numDisparities=D)
     L, R = synth.make_stream(5, n, W, H, D)
     assert np.array_equal(dL.cpu().numpy(), L) and np.array_equal(dR.cpu().numpy(), R)
+
+
+def test_morph_device_batch_and_timing_shape(pkg, oracle):
+    # device-resident batch through rtdm_morph_run_device: every frame equals the oracle's result
+    import torch
+    n, W, H = 5, 1280, 720
+    rng = np.random.default_rng(11)
+    masks = ((rng.random((n, H, W)) < 0.5) * 255).astype(np.uint8)
+    masks[:, 100:300, 200:700] = 255
+    d_in = torch.from_numpy(masks).cuda(); d_out = torch.empty_like(d_in)
+    mf = pkg.HIPMorphologicalFilter(W, H, 8, max_batch=2)      # forces chunking
+    mf.run_device(d_in, d_out, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.morph_open_close(masks[i])), i
