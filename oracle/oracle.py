@@ -14,6 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "librtdm_oracle.so")
 
 
+class SGMParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("blockSize", "minDisparity", "numDisparities", "P1", "P2", "uniquenessRatio",
+                                       "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
+
+
 class BMParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "preFilterCap", "blockSize", "minDisparity", "numDisparities", "textureThreshold",
@@ -62,6 +67,17 @@ def lib():
             getattr(L, n).restype = None
         L.orc_morph_open_close.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int]
         L.orc_morph_open_close.restype = None
+        u16p = C.POINTER(C.c_uint16)
+        L.orc_sgm_compute.argtypes = [C.POINTER(SGMParams), u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int, i16p, C.c_size_t]
+        L.orc_sgm_compute.restype = C.c_int
+        L.orc_sgm_pixel_cost.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
+        L.orc_sgm_pixel_cost.restype = None
+        L.orc_sgm_block_cost.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
+        L.orc_sgm_block_cost.restype = None
+        L.orc_sgm_aggregate.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
+        L.orc_sgm_aggregate.restype = None
+        L.orc_sgm_select.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i16p, C.c_size_t]
+        L.orc_sgm_select.restype = None
         _lib = L
     return _lib
 
@@ -158,3 +174,36 @@ def morph_open_close(img):
     img = np.ascontiguousarray(img, np.uint8); out = np.empty_like(img); H, W = img.shape
     lib().orc_morph_open_close(_p(img, C.c_uint8), W, _p(out, C.c_uint8), W, W, H)
     return out
+
+
+def make_sgm_params(blockSize=5, minDisparity=0, numDisparities=128, P1=600, P2=2400, uniquenessRatio=10,
+                    speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1):
+    """Defaults: P1/P2 from sgbm-sw.cpp:17-18, the rest the literals main.cpp:134-135 uses for the BM matcher."""
+    return SGMParams(blockSize, minDisparity, numDisparities, P1, P2, uniquenessRatio, speckleWindowSize,
+                     speckleRange, disp12MaxDiff)
+
+
+def sgm_compute(left, right, **kw):
+    left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+    H, W = left.shape
+    p = kw.pop("params", None) or make_sgm_params(**kw)
+    disp = np.empty((H, W), np.int16)
+    rc = lib().orc_sgm_compute(C.byref(p), _p(left, C.c_uint8), W, _p(right, C.c_uint8), W, W, H, _p(disp, C.c_int16), W * 2)
+    if rc != 0:
+        raise ValueError("orc_sgm_compute failed: %d" % rc)
+    return disp
+
+
+def sgm_stages(left, right, **kw):
+    """-> (pixel cost, block cost, aggregated S) as uint16 [H, W1, D] arrays, W1 = W - (minD + D) for minD >= 0."""
+    left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+    H, W = left.shape
+    p = kw.pop("params", None) or make_sgm_params(**kw)
+    D, minD = p.numDisparities, p.minDisparity
+    W1 = (W + min(minD, 0)) - max(minD + D, 0)
+    pix = np.zeros((H, W1, D), np.uint16); Cc = np.zeros_like(pix); S = np.zeros_like(pix)
+    L = lib()
+    L.orc_sgm_pixel_cost(_p(left, C.c_uint8), W, _p(right, C.c_uint8), W, W, H, minD, D, _p(pix, C.c_uint16))
+    L.orc_sgm_block_cost(_p(pix, C.c_uint16), W1, H, D, p.blockSize, _p(Cc, C.c_uint16))
+    L.orc_sgm_aggregate(_p(Cc, C.c_uint16), W1, H, D, p.P1, p.P2, _p(S, C.c_uint16))
+    return pix, Cc, S

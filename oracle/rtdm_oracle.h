@@ -91,6 +91,28 @@ void orc_dilate(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, in
 void orc_morph_open_close(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep,
                           int W, int H);
 
+/* ---- SGM-8 (BASELINE config 5; defined in sgm_oracle.c) ------------------------------------------
+ * Cost volumes are uint16 [H][W1][D] with W1 = the columns [minD+D, W+min(minD,0)). */
+typedef struct orc_sgm_params {
+    int blockSize;          /* odd; sgbm-sw.cpp passes the constructor's blockSize               */
+    int minDisparity;
+    int numDisparities;     /* multiple of 16                                                    */
+    int P1, P2;             /* sgbm-sw.cpp:17-18 -> 600, 2400                                    */
+    int uniquenessRatio;
+    int speckleWindowSize;
+    int speckleRange;       /* multiplied by 16 for filterSpeckles, as cv::StereoSGBM does        */
+    int disp12MaxDiff;      /* < 0 disables the left-right check                                  */
+} orc_sgm_params;
+
+void orc_sgm_pixel_cost(const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep, int W, int H,
+                        int minD, int D, uint16_t* cost);
+void orc_sgm_block_cost(const uint16_t* pix, int W1, int H, int D, int blockSize, uint16_t* C);
+void orc_sgm_aggregate(const uint16_t* C, int W1, int H, int D, int P1, int P2, uint16_t* S);
+void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int uniquenessRatio, int disp12MaxDiff,
+                    int16_t* disp, size_t dstep_elems);
+int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep,
+                    int W, int H, int16_t* disp, size_t dstep_bytes);
+
 #ifdef __cplusplus
 }
 #endif

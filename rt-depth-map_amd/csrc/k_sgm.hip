@@ -1,0 +1,244 @@
+// k_sgm.hip -- BASELINE config 5: semi-global matching with 8-path cost aggregation ("SGM-8"), the
+// device counterpart of the reference's SWSemiGlobalMatcher (/root/reference/stereo-matcher/
+// sgbm-sw.cpp:12-37 -> cv::StereoSGBM, P1 = 600, P2 = 2400).  The algorithm is the one defined by
+// oracle/sgm_oracle.c (integer arithmetic, tolerance 0 against that oracle; parity against a real
+// cv::StereoSGBM is unpinned).  Cost volumes live on the column domain [x0, x1) = [minD+D, W+min(minD,0))
+// and are laid out [frame][y][x - x0][d] with d fastest, so a wavefront's lanes = consecutive
+// disparities = one coalesced line per pixel.
+//
+//   k_sgm_grad   x-Sobel (vertical edge replication) clipped to +-15, + 15           (HBM bound)
+//   k_sgm_pix    Birchfield-Tomasi pixel cost, gradient + (intensity >> 2) -> u8      (lanes = d)
+//   k_sgm_box    blockSize x blockSize sum with clamped coordinates -> C (u16)
+//   k_sgm_path   one workgroup per path line, one thread per disparity: L_r recurrence with the
+//                neighbours and the line minimum exchanged through double-buffered LDS (one barrier
+//                per pixel), S += L_r; launched once per direction (8x)
+//   k_sgm_select one workgroup per row: winner-take-all, uniqueness, quadratic sub-pixel, left-right
+//                check on the integer winners (LDS votes), optional speckle-filter init
+#include "rtdm_kernels.h"
+#include "rtdm_device.h"
+
+namespace rtdm {
+
+static constexpr int FTZ = 15;
+
+__global__ __launch_bounds__(256) void k_sgm_grad(Plane8 L, Plane8 R, uint8_t* gl, uint8_t* gr, int W, int H, int n)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const int y = blockIdx.y;
+    int f = blockIdx.z;
+    const bool right = f >= n;
+    if (right) f -= n;
+    const Plane8 S = right ? R : L;
+    const uint8_t* img = S.base + (size_t)f * S.frame;
+    int v = FTZ;
+    if (x > 0 && x < W - 1) {
+        const uint8_t* r1 = img + (size_t)y * S.pitch;
+        const uint8_t* r0 = img + (size_t)(y > 0 ? y - 1 : y) * S.pitch;
+        const uint8_t* r2 = img + (size_t)(y < H - 1 ? y + 1 : y) * S.pitch;
+        const int g = ((int)r1[x + 1] - (int)r1[x - 1]) * 2 + ((int)r0[x + 1] - (int)r0[x - 1]) + ((int)r2[x + 1] - (int)r2[x - 1]);
+        v = min(max(g, -FTZ), FTZ) + FTZ;
+    }
+    (right ? gr : gl)[((size_t)f * H + y) * W + x] = (uint8_t)v;
+}
+
+__device__ __forceinline__ void bt_bounds(const uint8_t* row, int x, int W, int& v, int& lo, int& hi)
+{
+    v = row[x];
+    const int l = x > 0 ? (v + (int)row[x - 1]) / 2 : v;
+    const int r = x < W - 1 ? (v + (int)row[x + 1]) / 2 : v;
+    lo = min(min(l, r), v); hi = max(max(l, r), v);
+}
+
+// pixel cost, u8: one thread per (x, d); d fastest
+__global__ __launch_bounds__(256) void k_sgm_pix(Plane8 L, Plane8 R, const uint8_t* gl, const uint8_t* gr, uint8_t* pix,
+                                                 SGMGeom g)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D
+    if (idx >= (size_t)g.W1 * g.D) return;
+    const int d = (int)(idx % g.D), xi = (int)(idx / g.D);
+    const int y = blockIdx.y, f = blockIdx.z;
+    const int x = g.x0 + xi, xr = x - (d + g.minD);
+    const uint8_t* lrow = L.base + (size_t)f * L.frame + (size_t)y * L.pitch;
+    const uint8_t* rrow = R.base + (size_t)f * R.frame + (size_t)y * R.pitch;
+    const uint8_t* glrow = gl + ((size_t)f * g.H + y) * g.W;
+    const uint8_t* grrow = gr + ((size_t)f * g.H + y) * g.W;
+    int c = 0;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint8_t* a = pass ? lrow : glrow;
+        const uint8_t* b = pass ? rrow : grrow;
+        int u, u0, u1, v, v0, v1;
+        bt_bounds(a, x, g.W, u, u0, u1);
+        bt_bounds(b, xr, g.W, v, v0, v1);
+        const int c0 = max(0, max(u - v1, v0 - u));
+        const int c1 = max(0, max(v - u1, u0 - v));
+        c += min(c0, c1) >> (pass ? 2 : 0);
+    }
+    pix[(((size_t)f * g.H + y) * g.W1 + xi) * g.D + d] = (uint8_t)c;
+}
+
+__global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C, SGMGeom g, int r)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D
+    if (idx >= (size_t)g.W1 * g.D) return;
+    const int d = (int)(idx % g.D), xi = (int)(idx / g.D);
+    const int y = blockIdx.y, f = blockIdx.z;
+    const uint8_t* base = pix + (size_t)f * g.H * g.W1 * g.D;
+    int s = 0;
+    for (int dy = -r; dy <= r; ++dy) {
+        const int yy = min(max(y + dy, 0), g.H - 1);
+        for (int dx = -r; dx <= r; ++dx) {
+            const int xx = min(max(xi + dx, 0), g.W1 - 1);
+            s += base[((size_t)yy * g.W1 + xx) * g.D + d];
+        }
+    }
+    C[(((size_t)f * g.H + y) * g.W1 + xi) * g.D + d] = (uint16_t)s;
+}
+
+// wave-wide minimum (DPP), uniform result
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#define RTDM_DPP_MIN(ctrl, rmask) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, ctrl, rmask, 0xf, false))
+    RTDM_DPP_MIN(0xB1, 0xf); RTDM_DPP_MIN(0x4E, 0xf); RTDM_DPP_MIN(0x141, 0xf); RTDM_DPP_MIN(0x140, 0xf);
+    RTDM_DPP_MIN(0x142, 0xa); RTDM_DPP_MIN(0x143, 0xc);
+#undef RTDM_DPP_MIN
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// One workgroup per path line of direction (dx, dy); thread t = disparity t (blockDim = D rounded
+// up to a multiple of 64).  S (+)= L_r.
+__global__ __launch_bounds__(256) void k_sgm_path(const uint16_t* C, uint16_t* S, SGMGeom g, int dx, int dy, int P1, int P2,
+                                                  int first_dir)
+{
+    __shared__ int lbuf[2][256 + 2];      // L_r of the previous pixel, padded at d = -1 and d = D
+    __shared__ int wmin[2][4];
+    const int d = threadIdx.x, D = g.D, W1 = g.W1, H = g.H;
+    const int nw = (blockDim.x + 63) >> 6, wv = threadIdx.x >> 6;
+    const int f = blockIdx.y;
+    // start pixel of this line
+    int sx, sy;
+    const int line = blockIdx.x;
+    if (dy == 0) { sy = line; sx = dx > 0 ? 0 : W1 - 1; }
+    else if (dx == 0) { sx = line; sy = dy > 0 ? 0 : H - 1; }
+    else if (line < W1) { sx = line; sy = dy > 0 ? 0 : H - 1; }
+    else { const int k = line - W1 + 1; sx = dx > 0 ? 0 : W1 - 1; sy = dy > 0 ? k : H - 1 - k; }
+    const size_t fbase = (size_t)f * H * W1 * D;
+    const bool live = d < D;
+    const int BIG = 1 << 28;
+    int x = sx, y = sy, step = 0;
+    int cnext = (live && x >= 0 && x < W1 && y >= 0 && y < H) ? C[fbase + ((size_t)y * W1 + x) * D + d] : 0;
+    while (x >= 0 && x < W1 && y >= 0 && y < H) {
+        const size_t off = fbase + ((size_t)y * W1 + x) * D + d;
+        const int c = cnext;
+        const int nx = x + dx, ny = y + dy;
+        if (live && nx >= 0 && nx < W1 && ny >= 0 && ny < H) cnext = C[fbase + ((size_t)ny * W1 + nx) * D + d];   // prefetch
+        int l;
+        if (step == 0) {
+            l = c;
+        } else {
+            const int* pb = lbuf[(step - 1) & 1];
+            int mprev = wmin[(step - 1) & 1][0];
+            for (int q = 1; q < nw; ++q) mprev = min(mprev, wmin[(step - 1) & 1][q]);
+            const int best = min(min(pb[d + 1], mprev + P2), min(pb[d], pb[d + 2]) + P1);
+            l = c + best - mprev;
+        }
+        if (live) {
+            if (first_dir) S[off] = (uint16_t)l; else S[off] = (uint16_t)(S[off] + l);
+        }
+        int* cb = lbuf[step & 1];
+        cb[d + 1] = live ? l : BIG;
+        if (d == 0) { cb[0] = BIG; cb[D + 1] = BIG; }
+        const int m = wave_min_i32(live ? l : BIG);
+        if ((threadIdx.x & 63) == 0) wmin[step & 1][wv] = m;
+        __syncthreads();
+        x = nx; y = ny; ++step;
+    }
+}
+
+// winner-take-all + uniqueness + sub-pixel + left-right check; one workgroup per row
+template <bool SPK>
+__global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W disp, SGMGeom g, int uniq, int disp12MaxDiff,
+                                                    int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                                                    int16_t* headmap, int spkDiff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* key = (unsigned long long*)smem;     // W : (minS << 32 | x) votes per right column
+    int16_t* bdv = (int16_t*)(key + g.W);                    // W : integer winner + minD of column x (or minD-1)
+    int16_t* row = bdv + g.W;                                // W : disparity row
+    __shared__ int wsum[4];
+    const int y = blockIdx.y, f = blockIdx.z;
+    const int W = g.W, D = g.D, minD = g.minD, INV = (minD - 1) * 16;
+    for (int x = threadIdx.x; x < W; x += 256) { key[x] = ~0ull; bdv[x] = (int16_t)(minD - 1); row[x] = (int16_t)INV; }
+    __syncthreads();
+    const uint16_t* srow = S + (((size_t)f * g.H + y) * g.W1) * D;
+    for (int xi = threadIdx.x; xi < g.W1; xi += 256) {
+        const uint16_t* s = srow + (size_t)xi * D;
+        int mins = 0x7fffffff, bd = -1;
+        for (int d = 0; d < D; ++d) { const int v = s[d]; if (v < mins) { mins = v; bd = d; } }
+        bool rej = false;
+        const int lim = mins * 100;
+        for (int d = 0; d < D; ++d) rej |= (abs(d - bd) > 1) && ((int)s[d] * (100 - uniq) < lim);
+        if (rej) continue;
+        const int x = g.x0 + xi;
+        const int x2 = x - (bd + minD);
+        if (x2 >= 0 && x2 < W) atomicMin(&key[x2], ((unsigned long long)(unsigned)mins << 32) | (unsigned)x);
+        bdv[x] = (int16_t)(bd + minD);
+        int d16 = bd * 16;
+        if (bd > 0 && bd < D - 1) {
+            const int den = max((int)s[bd - 1] + (int)s[bd + 1] - 2 * mins, 1);
+            d16 += (((int)s[bd - 1] - (int)s[bd + 1]) * 16 + den) / (den * 2);
+        }
+        row[x] = (int16_t)(d16 + minD * 16);
+    }
+    __syncthreads();
+    int16_t* out = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    int16_t* fin = (int16_t*)(row + W);                      // W : final row (for the speckle init)
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int d1 = row[x];
+        if (disp12MaxDiff >= 0 && d1 != INV) {
+            const int da = d1 >> 4, db = (d1 + 15) >> 4;
+            const int xa = x - da, xb = x - db;
+            bool ba = false, bb = false;
+            if (xa >= 0 && xa < W && key[xa] != ~0ull) ba = abs((int)bdv[(unsigned)(key[xa] & 0xffffffffu)] - da) > disp12MaxDiff;
+            if (xb >= 0 && xb < W && key[xb] != ~0ull) bb = abs((int)bdv[(unsigned)(key[xb] & 0xffffffffu)] - db) > disp12MaxDiff;
+            if (ba && bb) d1 = INV;
+        }
+        out[x] = (int16_t)d1;
+        if (SPK) fin[x] = (int16_t)d1;
+    }
+    if (SPK) {
+        __syncthreads();
+        spk_row_init(fin, (int*)key, wsum, W, (f * g.H + y) * W, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff);
+    }
+}
+
+void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
+                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int n, hipStream_t stream)
+{
+    dim3 blk(256);
+    hipLaunchKernelGGL(k_sgm_grad, dim3((g.W + 255) / 256, g.H, 2 * n), blk, 0, stream, L, R, b.gl, b.gr, g.W, g.H, n);
+    const unsigned nxd = (unsigned)(((size_t)g.W1 * g.D + 255) / 256);
+    hipLaunchKernelGGL(k_sgm_pix, dim3(nxd, g.H, n), blk, 0, stream, L, R, b.gl, b.gr, b.pix, g);
+    hipLaunchKernelGGL(k_sgm_box, dim3(nxd, g.H, n), blk, 0, stream, b.pix, b.C, g, blockSize / 2);
+    static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1}};
+    const int threads = (g.D + 63) & ~63;
+    for (int k = 0; k < 8; ++k) {
+        const int dx = dirs[k][0], dy = dirs[k][1];
+        const int lines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
+        hipLaunchKernelGGL(k_sgm_path, dim3(lines, n), dim3(threads), 0, stream, b.C, b.S, g, dx, dy, P1, P2, k == 0 ? 1 : 0);
+    }
+    const bool speckle = speckleWindowSize > 0 && speckleRange >= 0;
+    const size_t lds = (size_t)g.W * (8 + 2 + 2 + 2);
+    if (speckle) {
+        hipLaunchKernelGGL(k_sgm_select<true>, dim3(1, g.H, n), blk, lds, stream, b.S, disp, g, uniq, disp12MaxDiff,
+                           b.label, b.size, b.runs, b.rowcnt, b.headmap, 16 * speckleRange);
+        launch_speckle(disp, b.label, b.size, b.runs, b.rowcnt, b.headmap, g.W, g.H, n, (g.minD - 1) * 16, speckleWindowSize,
+                       16 * speckleRange, true, 0, g.H, stream);
+    } else {
+        hipLaunchKernelGGL(k_sgm_select<false>, dim3(1, g.H, n), blk, lds, stream, b.S, disp, g, uniq, disp12MaxDiff,
+                           b.label, b.size, b.runs, b.rowcnt, b.headmap, 0);
+    }
+}
+
+}  // namespace rtdm

@@ -523,6 +523,121 @@ int rtdm_morph_run(rtdm_morph* mf, const uint8_t* in, size_t in_pitch, uint8_t* 
     return RTDM_OK;
 }
 
+// ---- SWSemiGlobalMatcher counterpart -------------------------------------------------------
+struct rtdm_sgm {
+    rtdm_sgm_params p;
+    int maxW, maxH, maxB, device;
+    hipStream_t stream;
+    uint8_t *dInL, *dInR;
+    int16_t* dOut;
+    SGMBuffers b;
+};
+
+void rtdm_sgm_default_params(rtdm_sgm_params* p, int numDisparities, int blockSize)
+{
+    if (!p) return;
+    p->blockSize = blockSize; p->minDisparity = 0; p->numDisparities = numDisparities; p->P1 = 600; p->P2 = 2400;
+    p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32; p->disp12MaxDiff = 1;
+}
+
+int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height, int max_batch, int device, rtdm_sgm** out)
+{
+    if (!params || !out) return RTDM_ERR_NULL;
+    *out = nullptr;
+    const rtdm_sgm_params& p = *params;
+    if (p.numDisparities <= 0 || p.numDisparities % 16 != 0 || p.blockSize < 1 || (p.blockSize & 1) == 0) return RTDM_ERR_BAD_PARAM;
+    if (p.P1 <= 0 || p.P2 <= p.P1 || p.uniquenessRatio < 0 || p.uniquenessRatio > 100) return RTDM_ERR_BAD_PARAM;
+    if (max_width <= 0 || max_height <= 0 || max_batch <= 0) return RTDM_ERR_BAD_SIZE;
+    if (p.numDisparities > 256 || max_width > 4096) return RTDM_ERR_UNSUPPORTED;
+    // the aggregated volume is uint16: 8 paths x (block cost + P2) must fit (pixel cost <= 30 + 63)
+    if (8L * ((long)p.blockSize * p.blockSize * 93 + p.P2) > 65535) return RTDM_ERR_UNSUPPORTED;
+    int rc = use_device(device);
+    if (rc) return rc;
+    rtdm_sgm* sg = new (std::nothrow) rtdm_sgm();
+    if (!sg) return RTDM_ERR_NOMEM;
+    sg->p = p; sg->maxW = max_width; sg->maxH = max_height; sg->maxB = max_batch; sg->device = device;
+    const size_t px = (size_t)max_width * max_height * max_batch;
+    const size_t vol = px * p.numDisparities;
+    hipError_t e = hipStreamCreateWithFlags(&sg->stream, hipStreamNonBlocking);
+    void** ptrs[] = {(void**)&sg->dInL, (void**)&sg->dInR, (void**)&sg->dOut, (void**)&sg->b.gl, (void**)&sg->b.gr,
+                     (void**)&sg->b.pix, (void**)&sg->b.C, (void**)&sg->b.S, (void**)&sg->b.label, (void**)&sg->b.size,
+                     (void**)&sg->b.runs, (void**)&sg->b.rowcnt, (void**)&sg->b.headmap};
+    const size_t sizes[] = {px, px, px * 2, px, px, vol, vol * 2, vol * 2, px * 4, px * 4, px * 4,
+                            (size_t)max_batch * max_height * 4, px * 2};
+    for (int i = 0; i < 13 && e == hipSuccess; ++i) e = hipMalloc(ptrs[i], sizes[i]);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("rtdm_sgm_create: ") + hipGetErrorString(e);
+        rtdm_sgm_destroy(sg);
+        return e == hipErrorOutOfMemory ? RTDM_ERR_NOMEM : RTDM_ERR_HIP;
+    }
+    *out = sg;
+    return RTDM_OK;
+}
+
+void rtdm_sgm_destroy(rtdm_sgm* sg)
+{
+    if (!sg) return;
+    (void)hipSetDevice(sg->device);
+    if (sg->stream) (void)hipStreamSynchronize(sg->stream);
+    void* bufs[] = {sg->dInL, sg->dInR, sg->dOut, sg->b.gl, sg->b.gr, sg->b.pix, sg->b.C, sg->b.S, sg->b.label, sg->b.size,
+                    sg->b.runs, sg->b.rowcnt, sg->b.headmap};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (sg->stream) (void)hipStreamDestroy(sg->stream);
+    delete sg;
+}
+
+static int sgm_chunk(rtdm_sgm* sg, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s)
+{
+    const rtdm_sgm_params& p = sg->p;
+    SGMGeom g;
+    g.W = W; g.H = H; g.D = p.numDisparities; g.minD = p.minDisparity;
+    g.x0 = std::max(g.minD + g.D, 0);
+    g.W1 = (W + std::min(g.minD, 0)) - g.x0;
+    if (g.W1 <= 0) { launch_fill16(disp, 0, W, 0, H, n, (g.minD - 1) * 16, s); return RTDM_OK; }
+    launch_sgm(L, R, disp, g, sg->b, p.blockSize, p.P1, p.P2, p.uniquenessRatio, p.disp12MaxDiff, p.speckleWindowSize,
+               p.speckleRange, n, s);
+    HIPC(hipGetLastError());
+    return RTDM_OK;
+}
+
+int rtdm_sgm_compute_device(rtdm_sgm* sg, int n, const uint8_t* d_left, const uint8_t* d_right, size_t pitch,
+                            size_t frame_stride, int width, int height, int16_t* d_disp, size_t disp_pitch,
+                            size_t disp_frame_stride, void* hip_stream)
+{
+    if (!sg || !d_left || !d_right || !d_disp) return RTDM_ERR_NULL;
+    if (n <= 0 || width <= 0 || height <= 0 || width > sg->maxW || height > sg->maxH) return RTDM_ERR_BAD_SIZE;
+    if (pitch < (size_t)width || disp_pitch < (size_t)width * 2 || (disp_pitch & 1) || (disp_frame_stride & 1)) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(sg->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : sg->stream;
+    for (int i0 = 0; i0 < n; i0 += sg->maxB) {
+        const int m = std::min(sg->maxB, n - i0);
+        Plane8 L{d_left + (size_t)i0 * frame_stride, pitch, frame_stride}, R{d_right + (size_t)i0 * frame_stride, pitch, frame_stride};
+        Plane16W O{d_disp + (size_t)i0 * (disp_frame_stride / 2), disp_pitch / 2, disp_frame_stride / 2};
+        int rc = sgm_chunk(sg, m, L, R, width, height, O, s);
+        if (rc) return rc;
+    }
+    return RTDM_OK;
+}
+
+int rtdm_sgm_compute(rtdm_sgm* sg, const uint8_t* left, size_t left_pitch, const uint8_t* right, size_t right_pitch,
+                     int width, int height, int16_t* disp, size_t disp_pitch)
+{
+    if (!sg || !left || !right || !disp) return RTDM_ERR_NULL;
+    if (width <= 0 || height <= 0 || width > sg->maxW || height > sg->maxH) return RTDM_ERR_BAD_SIZE;
+    if (left_pitch < (size_t)width || right_pitch < (size_t)width || disp_pitch < (size_t)width * 2) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(sg->device));
+    hipStream_t s = sg->stream;
+    HIPC(hipMemcpy2DAsync(sg->dInL, width, left, left_pitch, width, height, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpy2DAsync(sg->dInR, width, right, right_pitch, width, height, hipMemcpyHostToDevice, s));
+    Plane8 L{sg->dInL, (size_t)width, (size_t)width * height}, R{sg->dInR, (size_t)width, (size_t)width * height};
+    Plane16W O{sg->dOut, (size_t)width, (size_t)width * height};
+    int rc = sgm_chunk(sg, 1, L, R, width, height, O, s);
+    if (rc) return rc;
+    HIPC(hipMemcpy2DAsync(disp, disp_pitch, sg->dOut, (size_t)width * 2, (size_t)width * 2, height, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    return RTDM_OK;
+}
+
 // ---- synthetic stream ------------------------------------------------------------------------
 int rtdm_synth_pairs_device(uint64_t seed, int first_frame, int n, int width, int height, int numDisparities,
                             uint8_t* d_left, uint8_t* d_right, size_t pitch, size_t frame_stride, int device,

@@ -1,0 +1,111 @@
+// rtdm_device.h -- device-side helpers shared by the row kernels (k_basic.hip, k_sgm.hip):
+// workgroup scans over a row held in LDS, union-find primitives, the speckle filter's per-row init.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtdm {
+
+// Scan element = (number of run heads so far) << 16 | (x of the nearest head to the left + 1):
+// one pass yields both the head of every pixel and the compact index of every run.
+struct OpHead {
+    static __device__ int id() { return 0; }
+    static __device__ int f(int a, int b) { return (int)(((unsigned)a & 0xffff0000u) + ((unsigned)b & 0xffff0000u)) | max(a & 0xffff, b & 0xffff); }
+};
+
+// Inclusive scan of v[0..W) (int32 in LDS) in place.  Whole workgroup; ends with a barrier.
+template <typename Op>
+__device__ __forceinline__ void row_scan(int* v, int W, int* wsum)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int CH = (W + 255) >> 8;
+    const int x0 = tid * CH;
+    int run = Op::id();
+    for (int k = 0; k < CH; ++k) {
+        const int x = x0 + k;
+        if (x < W) { run = Op::f(run, v[x]); v[x] = run; }
+    }
+    int t = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(t, o);
+        if (lane >= o) t = Op::f(t, u);
+    }
+    __syncthreads();                 // previous users of wsum are done
+    if (lane == 63) wsum[wv] = t;
+    __syncthreads();
+    int excl = __shfl_up(t, 1);
+    if (lane == 0) excl = Op::id();
+    for (int q = 0; q < wv; ++q) excl = Op::f(excl, wsum[q]);
+    for (int k = 0; k < CH; ++k) {
+        const int x = x0 + k;
+        if (x < W) v[x] = Op::f(v[x], excl);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ bool conn(int a, int b, int newVal, int maxDiff)
+{ return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
+
+__device__ __forceinline__ int ld_relaxed(const int32_t* p)
+{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_relaxed(int32_t* p, int v)
+{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int uf_find(int32_t* parent, int x)   // with path halving
+{
+    for (;;) {
+        const int p = ld_relaxed(&parent[x]);
+        if (p == x) return x;
+        const int gp = ld_relaxed(&parent[p]);
+        if (gp == p) return p;
+        st_relaxed(&parent[x], gp);
+        x = gp;
+    }
+}
+
+__device__ __forceinline__ void uf_union(int32_t* parent, int a, int b)
+{
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }   // a > b: hang a under b
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;                                         // a was no longer a root; retry from its parent
+    }
+}
+
+// Speckle "init" for one row held in LDS (d[0..W)): finds the horizontal runs, makes every run head
+// its own parent with the run length as its size, appends (x | len << 16) to the row's run list and
+// writes the per-pixel head map (x of the run head, int16) that the merge step reads.
+// sc is a W-element int32 scratch array.  Whole workgroup.
+__device__ __forceinline__ void spk_row_init(const int16_t* d, int* sc, int* wsum, int W, int base,
+                                             int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                                             int16_t* headmap, int newVal, int maxDiff)
+{
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int v = d[x];
+        const bool head = v != newVal && !(x > 0 && conn(v, d[x - 1], newVal, maxDiff));
+        sc[x] = head ? ((1 << 16) | (x + 1)) : 0;
+    }
+    __syncthreads();
+    row_scan<OpHead>(sc, W, wsum);
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int v = d[x];
+        const int h = (sc[x] & 0xffff) - 1;
+        headmap[base + x] = (int16_t)h;
+        if (v == newVal) continue;
+        const bool last = (x == W - 1) || !conn(v, d[x + 1], newVal, maxDiff);
+        if (!last) continue;
+        const int len = x - h + 1;
+        label[base + h] = base + h;
+        size[base + h] = len;
+        runs[base + (sc[x] >> 16) - 1] = (uint32_t)h | ((uint32_t)len << 16);
+    }
+    if (threadIdx.x == 0) *rowcnt = sc[W - 1] >> 16;
+}
+
+}  // namespace rtdm

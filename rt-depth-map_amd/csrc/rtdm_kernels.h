@@ -72,6 +72,17 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
 void launch_morph_open_close(Plane8 in, Plane8W out, uint8_t* tmp0, uint8_t* tmp1, int W, int H,
                              int n, hipStream_t stream);
 
+// SGM-8 (BASELINE config 5).  Cost volumes live on the column domain [x0, x0+W1).
+struct SGMGeom { int W, H, D, minD, x0, W1; };
+struct SGMBuffers {
+    uint8_t *gl, *gr;        // gradient images           [n][H][W]
+    uint8_t* pix;            // pixel cost                 [n][H][W1][D]
+    uint16_t *C, *S;         // block cost, aggregated     [n][H][W1][D]
+    int32_t *label, *size, *rowcnt; uint32_t* runs; int16_t* headmap;   // speckle filter workspace
+};
+void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
+                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int n, hipStream_t stream);
+
 // Synthetic stream generator (bit-identical to synth.py).
 void launch_synth(uint64_t seed, int first_frame, int n, int W, int H, int D, Plane8W L, Plane8W R,
                   void* param_scratch, hipStream_t stream);

@@ -92,6 +92,51 @@ class HIPMatcher:
         return B.lib().rtdm_bm_search_variant(self._h).decode()
 
 
+class HIPSemiGlobalMatcher:
+    """BlockMatcher over rtdm_sgm_*; constructor shape of SWSemiGlobalMatcher
+    (include/stereo-matcher/sgbm-sw.h:27-28): blockSize, minDisparity, numOfDisparities, uniquenessRatio,
+    speckleWindowSize, speckleRange, disp12MaxDiff; P1/P2 are the literals of sgbm-sw.cpp:17-18."""
+
+    def __init__(self, blockSize=5, minDisparity=0, numOfDisparities=128, uniquenessRatio=10, speckleWindowSize=100,
+                 speckleRange=32, disp12MaxDiff=1, P1=600, P2=2400, width=1280, height=720, max_batch=1, device=0):
+        self._h = C.c_void_p()
+        self.params = B.SGMParams(blockSize, minDisparity, numOfDisparities, P1, P2, uniquenessRatio, speckleWindowSize,
+                                  speckleRange, disp12MaxDiff)
+        B.check(B.lib().rtdm_sgm_create(C.byref(self.params), width, height, max_batch, device, C.byref(self._h)),
+                "rtdm_sgm_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            B.lib().rtdm_sgm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def setROI1(self, roi):     # no-ops in the reference (sgbm-sw.h:32-33)
+        pass
+
+    def setROI2(self, roi):
+        pass
+
+    @property
+    def filtered(self):
+        return (self.params.minDisparity - 1) * 16
+
+    def compute(self, left, right):
+        assert left.dtype == np.uint8 and right.dtype == np.uint8 and left.shape == right.shape
+        assert left.ndim == 2 and left.strides[1] == 1 and right.strides[1] == 1
+        H, W = left.shape
+        disp = np.empty((H, W), np.int16)
+        B.check(B.lib().rtdm_sgm_compute(self._h, left.ctypes.data, left.strides[0], right.ctypes.data,
+                                         right.strides[0], W, H, disp.ctypes.data, W * 2), "rtdm_sgm_compute")
+        return disp
+
+    def compute_device(self, d_left, d_right, d_disp, stream=None):
+        n, H, W = d_left.shape
+        B.check(B.lib().rtdm_sgm_compute_device(self._h, n, d_left.data_ptr(), d_right.data_ptr(), W, W * H, W, H,
+                                                d_disp.data_ptr(), W * 2, W * H * 2, stream), "rtdm_sgm_compute_device")
+
+
 class HIPMorphologicalFilter:
     """VideoFilterDevice (filter/filter.h:13-37) over rtdm_morph_*; ctor shape of mf-sw.cpp:10-17."""
 

@@ -195,3 +195,108 @@ def morph(img, dilate):
 
 def morph_open_close(img):
     return morph(morph(morph(morph(img, False), True), True), False)
+
+
+# ---- SGM-8 (BASELINE config 5), second implementation, straight from the definition -----------------
+def _sgm_grad(img):
+    img = img.astype(np.int64)
+    H, W = img.shape
+    up = np.vstack([img[:1], img[:-1]]); dn = np.vstack([img[1:], img[-1:]])
+    g = np.full((H, W), 15, np.int64)
+    v = (img[:, 2:] - img[:, :-2]) * 2 + (up[:, 2:] - up[:, :-2]) + (dn[:, 2:] - dn[:, :-2])
+    g[:, 1:W - 1] = np.clip(v, -15, 15) + 15
+    return g
+
+
+def _bt_bounds(a):
+    """per-pixel (value, min, max) of the half-sample interval, integer halves, C truncation == floor here"""
+    a = a.astype(np.int64)
+    left = np.concatenate([a[:, :1], (a[:, 1:] + a[:, :-1]) // 2], axis=1)
+    right = np.concatenate([(a[:, :-1] + a[:, 1:]) // 2, a[:, -1:]], axis=1)
+    return a, np.minimum(np.minimum(left, right), a), np.maximum(np.maximum(left, right), a)
+
+
+def sgm_volumes(L, R, D, minD=0, blockSize=5, P1=600, P2=2400):
+    H, W = L.shape
+    x0, x1 = max(minD + D, 0), W + min(minD, 0)
+    W1 = x1 - x0
+    pix = np.zeros((H, W1, D), np.int64)
+    for a, b, sh in ((_sgm_grad(L), _sgm_grad(R), 0), (L, R, 2)):
+        u, u0, u1 = _bt_bounds(a)
+        v, v0, v1 = _bt_bounds(b)
+        xs = np.arange(x0, x1)
+        for d in range(D):
+            xr = xs - (d + minD)
+            c0 = np.maximum(0, np.maximum(u[:, xs] - v1[:, xr], v0[:, xr] - u[:, xs]))
+            c1 = np.maximum(0, np.maximum(v[:, xr] - u1[:, xs], u0[:, xs] - v[:, xr]))
+            pix[:, :, d] += np.minimum(c0, c1) >> sh
+    r = blockSize // 2
+    C = np.zeros_like(pix)
+    yy = np.arange(H); xx = np.arange(W1)
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            C += pix[np.clip(yy + dy, 0, H - 1)[:, None], np.clip(xx + dx, 0, W1 - 1)[None, :]]
+    S = np.zeros_like(C)
+    for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, 1), (1, -1), (-1, -1)):
+        Lr = np.zeros_like(C)
+        ys = range(H) if dy >= 0 else range(H - 1, -1, -1)
+        xs_ = range(W1) if dx >= 0 else range(W1 - 1, -1, -1)
+        for y in ys:
+            for x in xs_:
+                px, py = x - dx, y - dy
+                if 0 <= px < W1 and 0 <= py < H:
+                    prev = Lr[py, px]
+                    m = prev.min()
+                    best = np.minimum(prev, m + P2)
+                    best[1:] = np.minimum(best[1:], prev[:-1] + P1)
+                    best[:-1] = np.minimum(best[:-1], prev[1:] + P1)
+                    Lr[y, x] = C[y, x] + best - m
+                else:
+                    Lr[y, x] = C[y, x]
+        S += Lr
+    return pix, C, S
+
+
+def sgm(L, R, numDisparities=32, minDisparity=0, blockSize=5, P1=600, P2=2400, uniquenessRatio=10,
+        speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1):
+    H, W = L.shape
+    D, minD = numDisparities, minDisparity
+    INV = (minD - 1) * 16
+    out = np.full((H, W), INV, np.int64)
+    x0, x1 = max(minD + D, 0), W + min(minD, 0)
+    if x1 - x0 <= 0:
+        return out.astype(np.int16)
+    _, _, S = sgm_volumes(L, R, D, minD, blockSize, P1, P2)
+    for y in range(H):
+        d2 = [minD - 1] * W; c2 = [None] * W
+        for x in range(x0, x1):
+            s = S[y, x - x0]
+            bd = int(np.argmin(s)); mins = int(s[bd])
+            far = np.abs(np.arange(D) - bd) > 1
+            if np.any(far & (s * (100 - uniquenessRatio) < mins * 100)):
+                continue
+            x2 = x - (bd + minD)
+            if 0 <= x2 < W and (c2[x2] is None or c2[x2] > mins):
+                c2[x2] = mins; d2[x2] = bd + minD
+            if 0 < bd < D - 1:
+                den = max(int(s[bd - 1]) + int(s[bd + 1]) - 2 * mins, 1)
+                num = (int(s[bd - 1]) - int(s[bd + 1])) * 16 + den
+                q = abs(num) // (den * 2) * (1 if num >= 0 else -1)      # C truncation
+                d16 = bd * 16 + q
+            else:
+                d16 = bd * 16
+            out[y, x] = d16 + minD * 16
+        if disp12MaxDiff >= 0:
+            row = out[y].copy()
+            for x in range(x0, x1):
+                d1 = int(row[x])
+                if d1 == INV:
+                    continue
+                da, db = d1 >> 4, (d1 + 15) >> 4
+                xa, xb = x - da, x - db
+                if (0 <= xa < W and d2[xa] >= minD and abs(d2[xa] - da) > disp12MaxDiff and
+                        0 <= xb < W and d2[xb] >= minD and abs(d2[xb] - db) > disp12MaxDiff):
+                    out[y, x] = INV
+    if speckleWindowSize > 0 and speckleRange >= 0:
+        out = speckle(out.astype(np.int16), INV, speckleWindowSize, 16 * speckleRange).astype(np.int64)
+    return out.astype(np.int16)

@@ -249,3 +249,30 @@ def test_morph_device_batch_and_timing_shape(pkg, oracle):
     got = d_out.cpu().numpy()
     for i in range(n):
         assert np.array_equal(got[i], oracle.morph_open_close(masks[i])), i
+
+
+# ---- SGM-8 (BASELINE config 5) ---------------------------------------------------------------
+# Integer algorithm defined by oracle/sgm_oracle.c: the stated tolerance against that oracle is 0
+# (exact equality); against a real cv::StereoSGBM the comparison is unpinned.
+@pytest.mark.parametrize("W,H,D,minD,bs", [(72, 28, 16, 0, 5), (200, 120, 32, 0, 5), (161, 75, 48, 0, 3), (150, 60, 32, 3, 5),
+                                           (150, 60, 32, -4, 5), (300, 100, 128, 0, 5), (96, 40, 16, 0, 7)])
+def test_sgm_matches_oracle(pkg, oracle, synth, W, H, D, minD, bs):
+    L, R = synth.make_pair(synth.STREAM_SEED + 700 + W, W, H, D)
+    for kw in (dict(), dict(disp12MaxDiff=-1, speckleWindowSize=0), dict(uniquenessRatio=0, speckleWindowSize=30, speckleRange=2)):
+        m = pkg.HIPSemiGlobalMatcher(blockSize=bs, minDisparity=minD, numOfDisparities=D, width=W, height=H, **kw)
+        got = m.compute(L, R)
+        m.close()
+        assert_same(got, oracle.sgm_compute(L, R, blockSize=bs, minDisparity=minD, numDisparities=D, **kw))
+
+
+def test_sgm_device_batch(pkg, oracle, synth):
+    import torch
+    n, W, H, D = 3, 320, 240, 64
+    L, R = synth.make_stream(40, n, W, H, D)
+    dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, max_batch=2)
+    m.compute_device(dL, dR, dD, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert_same(dD[i].cpu().numpy(), oracle.sgm_compute(L[i], R[i], numDisparities=D))
