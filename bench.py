@@ -59,13 +59,65 @@ def cpu_baseline(pkg, budget_s=12.0):
                       "(single thread: %.2f pairs/s over %d frames)" % (n, cores, m / d1, m)}
 
 
+def rccl_stream(args, pkg, torch, dist, rank, local_rank, world):
+    """BASELINE config 4: a root-sourced stream of independent pairs, block-partitioned over the ranks."""
+    sh = importlib.import_module("rt-depth-map_amd.sharding")
+    N = args.rccl_stream
+    dev = torch.device("cuda", local_rank)
+    st = torch.cuda.current_stream().cuda_stream
+    cap = max(sh.shard_sizes(N, world))
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=BLOCK, width=W, height=H, max_batch=min(cap, 128), device=local_rank)
+    left = right = None
+    if rank == 0:
+        left = torch.empty((N, H, W), dtype=torch.uint8, device=dev); right = torch.empty_like(left)
+        for i0 in range(0, N, 128):
+            n = min(128, N - i0)
+            pkg.synth_pairs_device(left[i0:i0 + n], right[i0:i0 + n], first_frame=i0, numDisparities=D, device=local_rank, stream=st)
+
+    def compute(L, R):
+        out = torch.empty(L.shape, dtype=torch.int16, device=dev)
+        m.compute_device(L.contiguous(), R.contiguous(), out, st)
+        return out
+
+    class _Solo:      # world == 1: same code path without a process group
+        @staticmethod
+        def get_world_size(): return 1
+        @staticmethod
+        def get_rank(): return 0
+        @staticmethod
+        def scatter(t, lst, src=0): t.copy_(lst[0])
+        @staticmethod
+        def gather(t, lst, dst=0): lst[0].copy_(t)
+    d = dist if dist is not None else _Solo
+    for _ in range(max(1, args.warmup)):
+        sh.scatter_compute_gather(d, left, right, N, (H, W), compute, dev, chunk=64)
+    torch.cuda.synchronize()
+    if dist is not None: dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = sh.scatter_compute_gather(d, left, right, N, (H, W), compute, dev, chunk=64)
+    torch.cuda.synchronize()
+    if dist is not None: dist.barrier()
+    el = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "root-sourced stereo-pairs/sec (BASELINE config 4), 1280x720 d=64 9x9", "value": round(N * args.steps / el, 1),
+                          "unit": "stereo-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "frames": N,
+                          "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
+                          "data": "synthetic", "dtype": "u8", "collectives": "scatter + gather (torch.distributed, backend nccl = RCCL)",
+                          "valid_fraction": round(float((out != m.filtered).float().mean().item()), 4)}))
+    if dist is not None: dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rccl-stream", type=int, default=0, metavar="FRAMES",
+                    help="BASELINE config 4 instead of the headline: rank 0 owns FRAMES pairs, scatter -> compute -> gather "
+                         "over torch.distributed (RCCL); reports root-sourced pairs/s")
     args = ap.parse_args()
 
     import torch
@@ -82,6 +134,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("rt-depth-map_amd")
+    if args.rccl_stream:
+        return rccl_stream(args, pkg, torch, dist, rank, local_rank, world)
     B = args.batch
     dev = torch.device("cuda", local_rank)
     dL = torch.empty((B, H, W), dtype=torch.uint8, device=dev)

@@ -345,8 +345,7 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     fg.rs = (nrows + strips - 1) / strips;
     strips = (nrows + fg.rs - 1) / fg.rs;
     const size_t ldsb = (size_t)(g.w + 2) * C::SLOT * 4;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_search_fast<D, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (ldsb > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_search_fast<D, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg);
 }
 

@@ -180,8 +180,7 @@ template <typename T, int TC>
 static void launch_generic_t(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n,
                              hipStream_t stream, int gx0, int gx1, size_t lds)
 {
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)k_search_generic<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_search_generic<T, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid((gx1 - gx0 + TC - 1) / TC, (g.vy1 - g.vy0 + RS - 1) / RS, n);
     hipLaunchKernelGGL((k_search_generic<T, TC>), grid, dim3(256), lds, stream, Lp, Rp, disp, (T*)cost, g, gx0, gx1);
 }

@@ -6,6 +6,7 @@
 #include "rtdm_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -26,11 +27,26 @@ static thread_local std::string g_hip_err;
 
 struct StageEvent { hipEvent_t a, b; int stage; int frames; };
 
+// A lane = one HIP stream plus its slice of the per-handle workspace.  A batch is cut into pieces that
+// alternate between two lanes, so that the latency-bound row kernels (left-right check, speckle
+// filter) of one piece run beside the VALU-bound SAD search of the other.
+struct Lane {
+    hipStream_t stream;
+    hipEvent_t done;
+    uint8_t *dLp, *dRp;
+    int32_t *dCost, *dLabel, *dSize, *dRowCnt;
+    uint32_t* dRuns;
+    int16_t* dHead;
+};
+
 struct rtdm_bm {
     rtdm_bm_params p;
     int maxW, maxH, maxB, device;
     int roi1[4], roi2[4];
     hipStream_t stream;
+    Lane lane[2];
+    int nlanes, laneB;             // frames per lane piece
+    hipEvent_t evIn;
     size_t ppitch;                 // pitch of the internal 8-bit planes
     uint8_t *dLp, *dRp;            // prefiltered planes   [maxB][maxH][ppitch]
     uint8_t *dInL, *dInR;          // staging for the host entry points
@@ -150,6 +166,22 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
         rtdm_bm_destroy(bm);
         return e == hipErrorOutOfMemory ? RTDM_ERR_NOMEM : RTDM_ERR_HIP;
     }
+    {   // lanes: slices of the workspace (lane 1 starts laneB frames in)
+        const char* env = getenv("RTDM_LANES");
+        bm->nlanes = (max_batch >= 2 && !(env && atoi(env) == 1)) ? 2 : 1;
+        bm->laneB = bm->nlanes == 2 ? (max_batch + 1) / 2 : max_batch;
+        HIPC(hipEventCreateWithFlags(&bm->evIn, hipEventDisableTiming));
+        for (int k = 0; k < bm->nlanes; ++k) {
+            Lane& ln = bm->lane[k];
+            const size_t fo = (size_t)k * bm->laneB;                       // first frame of the slice
+            const size_t po = fo * max_width * max_height;                 // in pixels
+            HIPC(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            HIPC(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+            ln.dLp = bm->dLp + fo * bm->ppitch * max_height; ln.dRp = bm->dRp + fo * bm->ppitch * max_height;
+            ln.dCost = bm->dCost + po; ln.dLabel = bm->dLabel + po; ln.dSize = bm->dSize + po;
+            ln.dRuns = bm->dRuns + po; ln.dHead = bm->dHead + po; ln.dRowCnt = bm->dRowCnt + fo * max_height;
+        }
+    }
     *out = bm;
     return RTDM_OK;
 }
@@ -159,6 +191,11 @@ void rtdm_bm_destroy(rtdm_bm* bm)
     if (!bm) return;
     (void)hipSetDevice(bm->device);
     if (bm->stream) (void)hipStreamSynchronize(bm->stream);
+    for (int k = 0; k < bm->nlanes; ++k) {
+        if (bm->lane[k].stream) { (void)hipStreamSynchronize(bm->lane[k].stream); (void)hipStreamDestroy(bm->lane[k].stream); }
+        if (bm->lane[k].done) (void)hipEventDestroy(bm->lane[k].done);
+    }
+    if (bm->evIn) (void)hipEventDestroy(bm->evIn);
     for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
     void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead};
     for (void* b : bufs) if (b) (void)hipFree(b);
@@ -235,7 +272,7 @@ static void stage_end(rtdm_bm* bm, hipStream_t s, StageEvent* ev)
 }
 
 // One chunk (n <= maxB) of device-resident frames, enqueued on `s`.
-static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s)
+static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s)
 {
     const rtdm_bm_params& p = bm->p;
     BMGeom g;
@@ -252,39 +289,39 @@ static int run_chunk(rtdm_bm* bm, int n, Plane8 L, Plane8 R, int W, int H, Plane
     if (!generic_search_supported(g, &u16)) return RTDM_ERR_UNSUPPORTED;
     {
         bm->variant = fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
-        Plane8W Lp{bm->dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{bm->dRp, bm->ppitch, bm->ppitch * (size_t)H};
+        Plane8W Lp{ln.dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{ln.dRp, bm->ppitch, bm->ppitch * (size_t)H};
         stage_begin(bm, RTDM_STAGE_PREFILTER, n, s, &ev);
         launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s);
         stage_end(bm, s, &ev);
-        Plane8 Lpr{bm->dLp, Lp.pitch, Lp.frame}, Rpr{bm->dRp, Rp.pitch, Rp.frame};
+        Plane8 Lpr{ln.dLp, Lp.pitch, Lp.frame}, Rpr{ln.dRp, Rp.pitch, Rp.frame};
         stage_begin(bm, RTDM_STAGE_SEARCH, n, s, &ev);
         if (fast) {
             int lx0, lx1, rx0, rx1;
             fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
-            launch_search_fast(Lpr, Rpr, disp, bm->dCost, g, n, s);
+            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s);
             if (border_search_supported(g)) {
-                launch_search_border(Lpr, Rpr, disp, bm->dCost, g, n, s, lx0, lx1, rx0, rx1);
+                launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, s, lx0, lx1, rx0, rx1);
             } else {
-                launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, lx0, lx1);
-                launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, rx0, rx1);
+                launch_search_generic(Lpr, Rpr, disp, ln.dCost, g, n, s, lx0, lx1);
+                launch_search_generic(Lpr, Rpr, disp, ln.dCost, g, n, s, rx0, rx1);
             }
         } else {
-            launch_search_generic(Lpr, Rpr, disp, bm->dCost, g, n, s, g.cx0 - g.lofs, g.cx1 - g.lofs);
+            launch_search_generic(Lpr, Rpr, disp, ln.dCost, g, n, s, g.cx0 - g.lofs, g.cx1 - g.lofs);
         }
         stage_end(bm, s, &ev);
     }
     const bool speckle = p.speckleRange >= 0 && p.speckleWindowSize > 0;
     const bool lr = p.disp12MaxDiff >= 0;
-    if (speckle) HIPC(hipMemsetAsync(bm->dRowCnt, 0, (size_t)n * H * sizeof(int32_t), s));
+    if (speckle) HIPC(hipMemsetAsync(ln.dRowCnt, 0, (size_t)n * H * sizeof(int32_t), s));
     if (lr) {
         stage_begin(bm, RTDM_STAGE_LRCHECK, n, s, &ev);
-        if (speckle) launch_lrcheck(disp, bm->dCost, g, p.disp12MaxDiff, n, s, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead, p.speckleRange);
-        else         launch_lrcheck(disp, bm->dCost, g, p.disp12MaxDiff, n, s);
+        if (speckle) launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, p.speckleRange);
+        else         launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s);
         stage_end(bm, s, &ev);
     }
     if (speckle) {
         stage_begin(bm, RTDM_STAGE_SPECKLE, n, s, &ev);
-        launch_speckle(disp, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead, W, H, n, g.filtered, p.speckleWindowSize,
+        launch_speckle(disp, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, W, H, n, g.filtered, p.speckleWindowSize,
                        p.speckleRange, lr, g.vy0, g.vy1, s);
         stage_end(bm, s, &ev);
     }
@@ -311,13 +348,34 @@ int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint
         return RTDM_ERR_BAD_SIZE;
     HIPC(hipSetDevice(bm->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : bm->stream;
-    for (int i0 = 0; i0 < n; i0 += bm->maxB) {
-        const int m = std::min(bm->maxB, n - i0);
+    const bool split = bm->nlanes == 2 && n >= 2;
+    if (!split) {
+        for (int i0 = 0; i0 < n; i0 += bm->laneB) {
+            const int m = std::min(bm->laneB, n - i0);
+            Plane8 L{d_left + (size_t)i0 * frame_stride, pitch, frame_stride};
+            Plane8 R{d_right + (size_t)i0 * frame_stride, pitch, frame_stride};
+            Plane16W O{d_disp + (size_t)i0 * (disp_frame_stride / 2), disp_pitch / 2, disp_frame_stride / 2};
+            rc = run_chunk(bm, bm->lane[0], m, L, R, width, height, O, s);
+            if (rc) return rc;
+        }
+        return RTDM_OK;
+    }
+    // two lanes: the caller's stream fans out to the lane streams and joins them again
+    HIPC(hipEventRecord(bm->evIn, s));
+    for (int k = 0; k < 2; ++k) HIPC(hipStreamWaitEvent(bm->lane[k].stream, bm->evIn, 0));
+    const int piece = std::min(bm->laneB, (n + 1) / 2);
+    int k = 0;
+    for (int i0 = 0; i0 < n; i0 += piece, k ^= 1) {
+        const int m = std::min(piece, n - i0);
         Plane8 L{d_left + (size_t)i0 * frame_stride, pitch, frame_stride};
         Plane8 R{d_right + (size_t)i0 * frame_stride, pitch, frame_stride};
         Plane16W O{d_disp + (size_t)i0 * (disp_frame_stride / 2), disp_pitch / 2, disp_frame_stride / 2};
-        rc = run_chunk(bm, m, L, R, width, height, O, s);
+        rc = run_chunk(bm, bm->lane[k], m, L, R, width, height, O, bm->lane[k].stream);
         if (rc) return rc;
+    }
+    for (int q = 0; q < 2; ++q) {
+        HIPC(hipEventRecord(bm->lane[q].done, bm->lane[q].stream));
+        HIPC(hipStreamWaitEvent(s, bm->lane[q].done, 0));
     }
     return RTDM_OK;
 }
@@ -335,8 +393,8 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
     hipStream_t s = bm->stream;
     const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
     const size_t opitch = (size_t)width * 2, oframe = opitch * (size_t)height;
-    for (int i0 = 0; i0 < n; i0 += bm->maxB) {
-        const int m = std::min(bm->maxB, n - i0);
+    for (int i0 = 0; i0 < n; i0 += bm->laneB) {
+        const int m = std::min(bm->laneB, n - i0);
         for (int i = 0; i < m; ++i) {
             HIPC(hipMemcpy2DAsync(bm->dInL + i * dframe, dpitch, left + (size_t)(i0 + i) * frame_stride, pitch,
                                   width, height, hipMemcpyHostToDevice, s));
@@ -345,7 +403,7 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
         }
         Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
         Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
-        rc = run_chunk(bm, m, L, R, width, height, O, s);
+        rc = run_chunk(bm, bm->lane[0], m, L, R, width, height, O, s);
         if (rc) return rc;
         for (int i = 0; i < m; ++i)
             HIPC(hipMemcpy2DAsync((uint8_t*)disp + (size_t)(i0 + i) * disp_frame_stride, disp_pitch,
@@ -379,7 +437,7 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
     HIPC(hipMemcpyAsync(bm->dInR, hR, dframe, hipMemcpyHostToDevice, s));
     Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
     Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
-    rc = run_chunk(bm, 1, L, R, width, height, O, s);
+    rc = run_chunk(bm, bm->lane[0], 1, L, R, width, height, O, s);
     if (rc) return rc;
     HIPC(hipMemcpyAsync(hD, bm->dOut, (size_t)width * height * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));

@@ -28,7 +28,10 @@ class HIPMatcher:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            B.lib().rtdm_bm_destroy(self._h)
+            try:
+                B.lib().rtdm_bm_destroy(self._h)
+            except TypeError:       # interpreter shutdown: the module globals are already gone
+                pass
             self._h = None
 
     __del__ = close
@@ -107,7 +110,10 @@ class HIPSemiGlobalMatcher:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            B.lib().rtdm_sgm_destroy(self._h)
+            try:
+                B.lib().rtdm_sgm_destroy(self._h)
+            except TypeError:
+                pass
             self._h = None
 
     __del__ = close
@@ -149,7 +155,10 @@ class HIPMorphologicalFilter:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            B.lib().rtdm_morph_destroy(self._h)
+            try:
+                B.lib().rtdm_morph_destroy(self._h)
+            except TypeError:
+                pass
             self._h = None
 
     __del__ = close
