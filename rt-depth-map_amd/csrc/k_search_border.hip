@@ -12,162 +12,33 @@
 //   * vertical sliding window through an LDS ring of the last w row-SADs per e;
 //   * selection with wave-level operations: min-reduce of the key sad<<8|e (first minimum),
 //     __any() for the uniqueness test, readlane for sad[mind +- 1].
-#include "rtdm_kernels.h"
+#include "rtdm_border.h"
 
 #include <cstdlib>
 
 namespace rtdm {
 
-static constexpr int RB = 8;   // rows staged per batch
-
-struct BorderGeom { int lx0, lx1, rx0, rx1, rs, rsp; };
-
-// Wave-wide unsigned minimum with DPP row operations (no LDS round trips); result is uniform.
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
-{
-#define RTDM_DPP_MIN(ctrl, rmask)                                                                      \
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, ctrl, rmask, 0xf, false))
-    RTDM_DPP_MIN(0xB1, 0xf);    // quad_perm [1,0,3,2]
-    RTDM_DPP_MIN(0x4E, 0xf);    // quad_perm [2,3,0,1]
-    RTDM_DPP_MIN(0x141, 0xf);   // row_half_mirror
-    RTDM_DPP_MIN(0x140, 0xf);   // row_mirror          -> every lane holds its 16-lane row minimum
-    RTDM_DPP_MIN(0x142, 0xa);   // row_bcast:15 into rows 1 and 3
-    RTDM_DPP_MIN(0x143, 0xc);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave minimum
-#undef RTDM_DPP_MIN
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-template <int NCH>
-__global__ __launch_bounds__(256) void k_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
-                                                       BMGeom g, BorderGeom bg)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int D = g.D, w = g.w, r = g.r, W = g.W;
-    const int nl = bg.lx1 - bg.lx0, ncols = nl + (bg.rx1 - bg.rx0);
-    const int wcol = blockIdx.x * 4 + wv;
-    if (wcol >= ncols) return;                       // no workgroup barrier anywhere below
-    const int x = wcol < nl ? bg.lx0 + wcol : bg.rx0 + (wcol - nl);
-    const int col = g.lofs + x;
-    if (col >= W) return;
-    const int ys0 = g.vy0 + blockIdx.y * bg.rs;
-    const int ys1 = min(ys0 + bg.rs, g.vy1);
-    const int f = blockIdx.z;
-    // per-wave LDS carve-up
-    const int rsp = bg.rsp;                                            // bytes per staged right row
-    const size_t per_wave = (size_t)RB * rsp + (size_t)RB * 32 + (size_t)w * (NCH * 64) * 2 + (size_t)w * 4;
-    unsigned char* base = smem + (size_t)wv * ((per_wave + 15) & ~(size_t)15);
-    uint8_t* Rbuf = base;                                              // RB x rsp
-    uint8_t* Lbuf = Rbuf + (size_t)RB * rsp;                           // RB x 32   (w <= 21 on this path)
-    uint16_t* Hring = (uint16_t*)(Lbuf + RB * 32);                     // w x (NCH*64)
-    int* Tring = (int*)(Hring + (size_t)w * (NCH * 64));               // w
-
-    const uint8_t* Lb = Lp.base + (size_t)f * Lp.frame;
-    const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
-    const int j0 = x - r;                                              // first sample index
-    const int rbmin = min(max(g.rofs + j0, 0), W - D);
-    const int rbmax = min(max(g.rofs + j0 + w - 1, 0), W - D);
-    const int span = rbmax - rbmin + D;                                // right bytes needed per row
-
-    for (int i = lane; i < w * NCH * 64; i += 64) Hring[i] = 0;
-    if (lane < w) Tring[lane] = 0;
-    int S[NCH];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) S[c] = 0;
-    int tsum = 0;
-    __builtin_amdgcn_wave_barrier();
-
-    const int nsteps = (ys1 - ys0) + w - 1;
-    int slot = 0;
-    int16_t* db = disp.base + (size_t)f * disp.frame_e;
-    for (int s0 = 0; s0 < nsteps; s0 += RB) {
-        const int nb = min(RB, nsteps - s0);
-        for (int b = 0; b < nb; ++b) {
-            const int row = ys0 - r + s0 + b;
-            const uint8_t* rrow = Rb + (size_t)row * Rp.pitch + rbmin;
-            for (int i = lane; i < span; i += 64) Rbuf[b * rsp + i] = rrow[i];
-            if (lane < w) Lbuf[b * 32 + lane] = Lb[(size_t)row * Lp.pitch + min(max(g.lofs + j0 + lane, 0), W - 1)];
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int b = 0; b < nb; ++b) {
-            const int s = s0 + b;
-            int t = 0;
-            unsigned h[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) h[c] = 0;
-            const uint8_t* lrow = Lbuf + b * 32;
-            const uint8_t* rrow = Rbuf + b * rsp + lane;              // staged span is padded: always in bounds
-#pragma unroll 3
-            for (int dx = 0; dx < w; ++dx) {
-                const unsigned lv = lrow[dx];
-                const int rbo = min(max(g.rofs + j0 + dx, 0), W - D) - rbmin;
-                t += abs((int)lv - g.cap);
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) h[c] = __builtin_amdgcn_sad_u8(lv, (unsigned)rrow[rbo + 64 * c], h[c]);
-            }
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int e = lane + 64 * c;
-                uint16_t* hp = &Hring[slot * (NCH * 64) + e];
-                const int old = *hp;
-                *hp = (uint16_t)h[c];
-                S[c] += (int)h[c] - old;
-            }
-            const int told = Tring[slot];
-            __builtin_amdgcn_wave_barrier();
-            if (lane == 0) Tring[slot] = t;
-            tsum += t - told;
-            slot = (slot + 1 == w) ? 0 : slot + 1;
-            if (s < w - 1) continue;
-
-            const int y = ys0 - r + s - r;
-            unsigned k = 0xffffffffu;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int e = lane + 64 * c;
-                if (e < D) k = min(k, ((unsigned)S[c] << 8) | (unsigned)e);
-            }
-            k = wave_min_u32(k);
-            const int m1 = (int)(k >> 8), a = (int)(k & 0xffu);
-            bool fail = tsum < g.tex;
-            if (g.uniq > 0) {
-                const int thresh = m1 + (m1 * g.uniq / 100);
-                bool hit = false;
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    const int e = lane + 64 * c;
-                    hit |= (e < D) && (e < a - 1 || e > a + 1) && S[c] <= thresh;
-                }
-                fail |= __any(hit) != 0;
-            }
-            const int ip = (a + 1 < D) ? a + 1 : D - 2;
-            const int in = (a > 0) ? a - 1 : 1;
-            int pp = 0, nn = 0;                                        // ip, in are wave-uniform
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if ((ip >> 6) == c) pp = __builtin_amdgcn_readlane(S[c], ip & 63);
-                if ((in >> 6) == c) nn = __builtin_amdgcn_readlane(S[c], in & 63);
-            }
-            if (lane == 0) {
-                int out = g.filtered;
-                if (!fail) {
-                    const int den = pp + nn - 2 * m1 + abs(pp - nn);
-                    const int v = (D - a - 1 + g.minD) * 256 + (den != 0 ? (pp - nn) * 256 / den : 0) + 15;
-                    out = v >> 4;
-                    if (g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = (uint16_t)m1;
-                }
-                if (g.mask_cols && (col < g.vx0 || col >= g.vx1)) out = g.filtered;
-                db[(size_t)y * disp.pitch_e + col] = (int16_t)out;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
 bool border_search_supported(const BMGeom& g)
 {
     return g.w <= 21 && g.D <= 256 && 2L * g.cap * g.w * g.w <= 65535;
+}
+
+// Geometry + LDS bytes of the border work; returns the grid (x = column groups, y = strips), 0 columns -> false.
+bool border_geometry(const BMGeom& g, int lx0, int lx1, int rx0, int rx1, BorderGeom* out, int* gx, int* gy, size_t* lds_bytes)
+{
+    const int ncols = max(0, lx1 - lx0) + max(0, rx1 - rx0);
+    if (ncols <= 0) return false;
+    BorderGeom bg;
+    bg.lx0 = lx0; bg.lx1 = max(lx1, lx0); bg.rx0 = rx0; bg.rx1 = max(rx1, rx0);
+    const int nrows = g.vy1 - g.vy0;
+    static int rs_env = 0;
+    if (!rs_env) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 32; if (rs_env < 8) rs_env = 32; }
+    bg.rs = rs_env;
+    bg.rsp = (g.D + g.w + 3 + 63 + 64) & ~3;       // + one chunk of slack for lanes with e >= D
+    const int nch = (g.D + 63) / 64;
+    const size_t per_wave = ((size_t)RB * bg.rsp + (size_t)RB * 32 + (size_t)g.w * (nch * 64) * 2 + (size_t)g.w * 4 + 15) & ~(size_t)15;
+    *out = bg; *gx = (ncols + 3) / 4; *gy = (nrows + bg.rs - 1) / bg.rs; *lds_bytes = per_wave * 4;
+    return true;
 }
 
 void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n,

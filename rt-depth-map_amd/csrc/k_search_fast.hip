@@ -18,7 +18,7 @@
 //   Only columns whose whole window is free of border clamping are handled here; the 2*(w/2)
 //   border columns go to the generic kernel (they are outside the valid rectangle but feed the
 //   left-right check).  Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
-#include "rtdm_kernels.h"
+#include "rtdm_border.h"
 
 #include <cstdlib>
 
@@ -37,6 +37,8 @@ struct FastGeom {
     int x0, nx;          // output-column range [x0, x0+nx) handled by this kernel
     int rs;              // output rows per workgroup
     uint32_t lastmask;   // byte mask of the last (partial) window piece
+    int tiles;           // workgroups with blockIdx.x >= tiles do the border columns (rtdm_border.h)
+    int bgx, bgy;        // grid of that border work (0 x 0: none)
 };
 
 template <int D, int NP>
@@ -104,11 +106,18 @@ __device__ __forceinline__ int div_trunc_small(int num, int den)   // den > 0, |
 
 template <int D, int NP>
 __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
-                                                     BMGeom g, FastGeom fg)
+                                                     BMGeom g, FastGeom fg, BorderGeom bg)
 {
     using C = FastCfg<D, NP>;
     constexpr int NG = C::NG, NR = C::NR, LWD = C::LWD, RWD = C::RWD, SLOT = C::SLOT, ITEMS = C::ITEMS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
+    if (blockIdx.x >= (unsigned)fg.tiles) {
+        // border columns: latency-bound, so they ride in the same grid and overlap the VALU-bound tiles
+        const int id = (blockIdx.x - fg.tiles) * gridDim.y + blockIdx.y;
+        if (id < fg.bgx * fg.bgy) border_body<(D + 63) / 64>((unsigned char*)lds, Lp, Rp, disp, cost, g, bg, id % fg.bgx, id / fg.bgx, blockIdx.z);
+        return;
+    }
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int phi = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -324,10 +333,12 @@ static bool fast_range(const BMGeom& g, int* x0, int* nx)
     return xh >= xl;
 }
 
+void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
+
 static int fast_np(const BMGeom& g) { return (g.w + 3) / 4; }
 
 template <int D, int NP>
-static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream)
+static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, bool fuse_border)
 {
     using C = FastCfg<D, NP>;
     FastGeom fg;
@@ -344,9 +355,20 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     strips = max(1, min(strips, (nrows + 15) / 16));
     fg.rs = (nrows + strips - 1) / strips;
     strips = (nrows + fg.rs - 1) / fg.rs;
-    const size_t ldsb = (size_t)(g.w + 2) * C::SLOT * 4;
+    size_t ldsb = (size_t)(g.w + 2) * C::SLOT * 4;
+    BorderGeom bg = {};
+    fg.tiles = tiles; fg.bgx = fg.bgy = 0;
+    int extra = 0;
+    if (fuse_border) {
+        int lx0, lx1, rx0, rx1; size_t blds = 0;
+        fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
+        if (border_geometry(g, lx0, lx1, rx0, rx1, &bg, &fg.bgx, &fg.bgy, &blds)) {
+            extra = (fg.bgx * fg.bgy + strips - 1) / strips;
+            ldsb = max(ldsb, blds);
+        }
+    }
     if (ldsb > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_search_fast<D, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg);
+    hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles + extra, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg, bg);
 }
 
 bool fast_search_supported(const BMGeom& g)
@@ -361,13 +383,13 @@ bool fast_search_supported(const BMGeom& g)
     return false;
 }
 
-void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream)
+void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, bool fuse_border)
 {
     const int np = fast_np(g);
-    if (g.D == 64 && np == 3) launch_one<64, 3>(Lp, Rp, disp, cost, g, n, stream);
-    else if (g.D == 32 && np == 2) launch_one<32, 2>(Lp, Rp, disp, cost, g, n, stream);
-    else if (g.D == 128 && np == 3) launch_one<128, 3>(Lp, Rp, disp, cost, g, n, stream);
-    else if (g.D == 192 && np == 4) launch_one<192, 4>(Lp, Rp, disp, cost, g, n, stream);
+    if (g.D == 64 && np == 3) launch_one<64, 3>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
+    else if (g.D == 32 && np == 2) launch_one<32, 2>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
+    else if (g.D == 128 && np == 3) launch_one<128, 3>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
+    else if (g.D == 192 && np == 4) launch_one<192, 4>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
 }
 
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1)

@@ -298,8 +298,11 @@ static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int
         if (fast) {
             int lx0, lx1, rx0, rx1;
             fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
-            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s);
-            if (border_search_supported(g)) {
+            static const bool separate = getenv("RTDM_SEPARATE_BORDER") != nullptr;   // A/B switch
+            const bool fuse = border_search_supported(g) && !separate;
+            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse);
+            if (fuse) {
+            } else if (border_search_supported(g)) {
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, s, lx0, lx1, rx0, rx1);
             } else {
                 launch_search_generic(Lpr, Rpr, disp, ln.dCost, g, n, s, lx0, lx1);
