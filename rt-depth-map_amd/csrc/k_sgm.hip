@@ -78,22 +78,43 @@ __global__ __launch_bounds__(256) void k_sgm_pix(Plane8 L, Plane8 R, const uint8
     pix[(((size_t)f * g.H + y) * g.W1 + xi) * g.D + d] = (uint8_t)c;
 }
 
-__global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C, SGMGeom g, int r)
+// block cost: thread = (x, d); walks down a strip of rows keeping the last 2R+1 horizontal sums in
+// registers, so every pixel-cost element is read (2R+1) times instead of (2R+1)^2 times
+template <int R>
+__global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C, SGMGeom g, int rows_per_strip)
 {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D
     if (idx >= (size_t)g.W1 * g.D) return;
     const int d = (int)(idx % g.D), xi = (int)(idx / g.D);
-    const int y = blockIdx.y, f = blockIdx.z;
-    const uint8_t* base = pix + (size_t)f * g.H * g.W1 * g.D;
-    int s = 0;
-    for (int dy = -r; dy <= r; ++dy) {
-        const int yy = min(max(y + dy, 0), g.H - 1);
-        for (int dx = -r; dx <= r; ++dx) {
-            const int xx = min(max(xi + dx, 0), g.W1 - 1);
-            s += base[((size_t)yy * g.W1 + xx) * g.D + d];
+    const int f = blockIdx.z;
+    const int y0 = blockIdx.y * rows_per_strip, y1 = min(y0 + rows_per_strip, g.H);
+    const uint8_t* base = pix + (size_t)f * g.H * g.W1 * g.D + d;
+    int xs[2 * R + 1];
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k) xs[k] = min(max(xi + k - R, 0), g.W1 - 1) * g.D;
+    const auto hsum = [&](int y) -> int {
+        const uint8_t* row = base + (size_t)min(max(y, 0), g.H - 1) * g.W1 * g.D;
+        int s = 0;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) s += row[xs[k]];
+        return s;
+    };
+    int ring[2 * R + 1];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k) { ring[k] = hsum(y0 - R + k); sum += ring[k]; }
+    uint16_t* out = C + (((size_t)f * g.H) * g.W1 + xi) * g.D + d;
+    for (int y = y0; y < y1; y += 2 * R + 1) {
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) {
+            if (y + k < y1) {
+                out[(size_t)(y + k) * g.W1 * g.D] = (uint16_t)sum;
+                const int h = hsum(y + k + R + 1);
+                sum += h - ring[k];
+                ring[k] = h;
+            }
         }
     }
-    C[(((size_t)f * g.H + y) * g.W1 + xi) * g.D + d] = (uint16_t)s;
 }
 
 // wave-wide minimum (DPP), uniform result
@@ -156,8 +177,10 @@ __global__ __launch_bounds__(256) void k_sgm_path(const uint16_t* C, uint16_t* S
     }
 }
 
-// winner-take-all + uniqueness + sub-pixel + left-right check; one workgroup per row
-template <bool SPK>
+// winner-take-all + uniqueness + sub-pixel + left-right check; one workgroup per row.  Each WAVE takes
+// every 4th pixel of the row with its LANES on the disparities (coalesced 2*D-byte reads of S): wave-min of
+// the key S << 8 | d (first minimum), __any() for the uniqueness test, readlane for S[d* +- 1].
+template <bool SPK, int NCH>
 __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W disp, SGMGeom g, int uniq, int disp12MaxDiff,
                                                     int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                                                     int16_t* headmap, int spkDiff)
@@ -169,27 +192,49 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
     __shared__ int wsum[4];
     const int y = blockIdx.y, f = blockIdx.z;
     const int W = g.W, D = g.D, minD = g.minD, INV = (minD - 1) * 16;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int x = threadIdx.x; x < W; x += 256) { key[x] = ~0ull; bdv[x] = (int16_t)(minD - 1); row[x] = (int16_t)INV; }
     __syncthreads();
     const uint16_t* srow = S + (((size_t)f * g.H + y) * g.W1) * D;
-    for (int xi = threadIdx.x; xi < g.W1; xi += 256) {
+    for (int xi = wv; xi < g.W1; xi += 4) {
         const uint16_t* s = srow + (size_t)xi * D;
-        int mins = 0x7fffffff, bd = -1;
-        for (int d = 0; d < D; ++d) { const int v = s[d]; if (v < mins) { mins = v; bd = d; } }
-        bool rej = false;
-        const int lim = mins * 100;
-        for (int d = 0; d < D; ++d) rej |= (abs(d - bd) > 1) && ((int)s[d] * (100 - uniq) < lim);
-        if (rej) continue;
-        const int x = g.x0 + xi;
-        const int x2 = x - (bd + minD);
-        if (x2 >= 0 && x2 < W) atomicMin(&key[x2], ((unsigned long long)(unsigned)mins << 32) | (unsigned)x);
-        bdv[x] = (int16_t)(bd + minD);
-        int d16 = bd * 16;
-        if (bd > 0 && bd < D - 1) {
-            const int den = max((int)s[bd - 1] + (int)s[bd + 1] - 2 * mins, 1);
-            d16 += (((int)s[bd - 1] - (int)s[bd + 1]) * 16 + den) / (den * 2);
+        int v[NCH];
+        unsigned k = 0x7fffffffu;                            // (reduced as signed: keep the sentinel positive)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = lane + 64 * c;
+            v[c] = d < D ? (int)s[d] : 0x7fff;
+            if (d < D) k = min(k, ((unsigned)v[c] << 8) | (unsigned)d);
         }
-        row[x] = (int16_t)(d16 + minD * 16);
+        k = (unsigned)wave_min_i32((int)k);                  // keys are < 2^24: signed min is fine
+        const int mins = (int)(k >> 8), bd = (int)(k & 0xffu);
+        bool hit = false;
+        const int lim = mins * 100;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int d = lane + 64 * c;
+            hit |= d < D && abs(d - bd) > 1 && v[c] * (100 - uniq) < lim;
+        }
+        if (__any(hit)) continue;                             // wave-uniform
+        const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
+        int sp = 0, sn = 0;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if ((ip >> 6) == c) sp = __builtin_amdgcn_readlane(v[c], ip & 63);
+            if ((in >> 6) == c) sn = __builtin_amdgcn_readlane(v[c], in & 63);
+        }
+        if (lane == 0) {
+            const int x = g.x0 + xi;
+            const int x2 = x - (bd + minD);
+            if (x2 >= 0 && x2 < W) atomicMin(&key[x2], ((unsigned long long)(unsigned)mins << 32) | (unsigned)x);
+            bdv[x] = (int16_t)(bd + minD);
+            int d16 = bd * 16;
+            if (bd > 0 && bd < D - 1) {
+                const int den = max(sn + sp - 2 * mins, 1);
+                d16 += ((sn - sp) * 16 + den) / (den * 2);
+            }
+            row[x] = (int16_t)(d16 + minD * 16);
+        }
     }
     __syncthreads();
     int16_t* out = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
@@ -213,6 +258,16 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
     }
 }
 
+template <bool SPK>
+static void launch_select(int nch, dim3 grid, size_t lds, hipStream_t stream, const uint16_t* S, Plane16W disp, const SGMGeom& g,
+                          int uniq, int md, const SGMBuffers& b, int spkDiff)
+{
+    dim3 blk(256);
+#define RTDM_SEL(N) hipLaunchKernelGGL((k_sgm_select<SPK, N>), grid, blk, lds, stream, S, disp, g, uniq, md, b.label, b.size, b.runs, b.rowcnt, b.headmap, spkDiff)
+    switch (nch) { case 1: RTDM_SEL(1); break; case 2: RTDM_SEL(2); break; case 3: RTDM_SEL(3); break; default: RTDM_SEL(4); break; }
+#undef RTDM_SEL
+}
+
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
                 int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int n, hipStream_t stream)
 {
@@ -220,7 +275,16 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     hipLaunchKernelGGL(k_sgm_grad, dim3((g.W + 255) / 256, g.H, 2 * n), blk, 0, stream, L, R, b.gl, b.gr, g.W, g.H, n);
     const unsigned nxd = (unsigned)(((size_t)g.W1 * g.D + 255) / 256);
     hipLaunchKernelGGL(k_sgm_pix, dim3(nxd, g.H, n), blk, 0, stream, L, R, b.gl, b.gr, b.pix, g);
-    hipLaunchKernelGGL(k_sgm_box, dim3(nxd, g.H, n), blk, 0, stream, b.pix, b.C, g, blockSize / 2);
+    {
+        const int rps = 48, strips = (g.H + rps - 1) / rps;
+        const dim3 bgrid(nxd, strips, n);
+        switch (blockSize / 2) {
+            case 0: hipLaunchKernelGGL(k_sgm_box<0>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+            case 1: hipLaunchKernelGGL(k_sgm_box<1>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+            case 2: hipLaunchKernelGGL(k_sgm_box<2>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+            default: hipLaunchKernelGGL(k_sgm_box<3>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+        }
+    }
     static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1}};
     const int threads = (g.D + 63) & ~63;
     for (int k = 0; k < 8; ++k) {
@@ -231,13 +295,11 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     const bool speckle = speckleWindowSize > 0 && speckleRange >= 0;
     const size_t lds = (size_t)g.W * (8 + 2 + 2 + 2);
     if (speckle) {
-        hipLaunchKernelGGL(k_sgm_select<true>, dim3(1, g.H, n), blk, lds, stream, b.S, disp, g, uniq, disp12MaxDiff,
-                           b.label, b.size, b.runs, b.rowcnt, b.headmap, 16 * speckleRange);
+        launch_select<true>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, disp, g, uniq, disp12MaxDiff, b, 16 * speckleRange);
         launch_speckle(disp, b.label, b.size, b.runs, b.rowcnt, b.headmap, g.W, g.H, n, (g.minD - 1) * 16, speckleWindowSize,
                        16 * speckleRange, true, 0, g.H, stream);
     } else {
-        hipLaunchKernelGGL(k_sgm_select<false>, dim3(1, g.H, n), blk, lds, stream, b.S, disp, g, uniq, disp12MaxDiff,
-                           b.label, b.size, b.runs, b.rowcnt, b.headmap, 0);
+        launch_select<false>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, disp, g, uniq, disp12MaxDiff, b, 0);
     }
 }
 
