@@ -5,6 +5,8 @@
 #include "rtdm_kernels.h"
 #include "rtdm_device.h"
 
+#include <cstdlib>
+
 namespace rtdm {
 
 // ---------------------------------------------------------------------------------------------
@@ -130,47 +132,45 @@ void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int val
 // snapshot, so the in-place update cannot race.  Columns outside the valid rectangle are masked in
 // the same pass.  With SPK the final row is handed straight to the speckle filter's init step.
 // ---------------------------------------------------------------------------------------------
-template <bool SPK, typename CT>
+// KT = key type: 32-bit keys (cost << 16 | x) when the cost plane is 16-bit, else 64-bit (cost << 32 | x).
+template <bool SPK, typename CT, typename KT>
 __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, BMGeom g, int maxDiff16,
                                                  int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                                                  int16_t* headmap, int spkDiff)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned long long* key = (unsigned long long*)smem;            // W
-    int16_t* snap = (int16_t*)(smem + (size_t)g.W * 8);             // W
-    int16_t* fin = snap + g.W;                                      // W (final row)
+    constexpr int KSH = sizeof(KT) * 4;                               // bit position of the cost inside a key
+    constexpr KT NONE = (KT)~(KT)0, XMASK = ((KT)1 << KSH) - 1;
+    int* sc = (int*)smem;                                             // W ints: keys first, then scan scratch
+    KT* key = (KT*)smem;                                              // (64-bit keys need 2W ints)
+    int16_t* snap = (int16_t*)(smem + (size_t)g.W * (sizeof(KT) > 4 ? 8 : 4));   // W
+    int16_t* fin = snap + g.W;                                        // W (final row)
     __shared__ int wsum[4];
+    const int nt = blockDim.x;
     const int y = g.vy0 + blockIdx.y;
     const int f = blockIdx.z;
     int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     const CT* crow = cost + ((size_t)f * g.H + y) * g.W;
     const int W = g.W, INV = g.filtered;
-    for (int x = threadIdx.x; x < W; x += 256) { key[x] = ~0ull; snap[x] = row[x]; }
+    for (int x = threadIdx.x; x < W; x += nt) { key[x] = NONE; snap[x] = row[x]; }
     __syncthreads();
     const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
-    for (int x = minX1 + threadIdx.x; x < maxX1; x += 256) {
+    for (int x = minX1 + threadIdx.x; x < maxX1; x += nt) {
         const int d = snap[x];
         if (d == INV) continue;
         const int x2 = x - ((d + 8) >> 4);
         if (x2 < 0 || x2 >= W) continue;
-        const unsigned long long k = ((unsigned long long)(unsigned)crow[x] << 32) | (unsigned)x;
-        atomicMin(&key[x2], k);
+        atomicMin(&key[x2], ((KT)(unsigned)crow[x] << KSH) | (KT)(unsigned)x);
     }
     __syncthreads();
-    for (int x = threadIdx.x; x < W; x += 256) {
+    for (int x = threadIdx.x; x < W; x += nt) {
         int d = snap[x];
         bool kill = (x < g.vx0 || x >= g.vx1);
         if (!kill && d != INV && x >= minX1 && x < maxX1) {
             const int x0 = x - (d >> 4), x1 = x - ((d + 15) >> 4);
             bool bad0 = false, bad1 = false;
-            if (x0 >= 0 && x0 < W && key[x0] != ~0ull) {
-                const int d2 = snap[(unsigned)(key[x0] & 0xffffffffu)];
-                bad0 = abs(d2 - d) > maxDiff16;
-            }
-            if (x1 >= 0 && x1 < W && key[x1] != ~0ull) {
-                const int d2 = snap[(unsigned)(key[x1] & 0xffffffffu)];
-                bad1 = abs(d2 - d) > maxDiff16;
-            }
+            if (x0 >= 0 && x0 < W && key[x0] != NONE) bad0 = abs((int)snap[(unsigned)(key[x0] & XMASK)] - d) > maxDiff16;
+            if (x1 >= 0 && x1 < W && key[x1] != NONE) bad1 = abs((int)snap[(unsigned)(key[x1] & XMASK)] - d) > maxDiff16;
             kill = bad0 && bad1;
         }
         if (kill && d != INV) { row[x] = (int16_t)INV; d = INV; }
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, 
     if (SPK) {
         __syncthreads();
         const int base = (f * g.H + y) * W;               // the keys are no longer needed: scan scratch
-        spk_row_init(fin, (int*)key, wsum, W, base, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff);
+        spk_row_init(fin, sc, wsum, W, base, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff);
     }
 }
 
@@ -187,17 +187,26 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
                     hipStream_t stream, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                     int16_t* headmap, int spkDiff)
 {
-    const size_t lds = (size_t)g.W * 12;
-    dim3 grid(1, g.vy1 - g.vy0, n), block(256);
+    // workgroup size is tunable (RTDM_LR_THREADS); 64 / 128 / 256 measured 0.85 / 0.48 / 0.49 ms per 64 frames
+    static int nt = 0;
+    if (!nt) { const char* e = getenv("RTDM_LR_THREADS"); nt = e ? atoi(e) : 256; if (nt != 64 && nt != 128 && nt != 256) nt = 256; }
+    dim3 grid(1, g.vy1 - g.vy0, n), block(nt);
     const int md = disp12MaxDiff * 16;
-    if (g.cost16) {
+    if (g.cost16 && g.W < 65536) {
+        const size_t lds = (size_t)g.W * 8;
         const uint16_t* c = (const uint16_t*)cost;
-        if (label) hipLaunchKernelGGL((k_lrcheck<true, uint16_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        else       hipLaunchKernelGGL((k_lrcheck<false, uint16_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        if (label) hipLaunchKernelGGL((k_lrcheck<true, uint16_t, uint32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL((k_lrcheck<false, uint16_t, uint32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+    } else if (g.cost16) {
+        const size_t lds = (size_t)g.W * 12;
+        const uint16_t* c = (const uint16_t*)cost;
+        if (label) hipLaunchKernelGGL((k_lrcheck<true, uint16_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL((k_lrcheck<false, uint16_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
     } else {
+        const size_t lds = (size_t)g.W * 12;
         const int32_t* c = (const int32_t*)cost;
-        if (label) hipLaunchKernelGGL((k_lrcheck<true, int32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        else       hipLaunchKernelGGL((k_lrcheck<false, int32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        if (label) hipLaunchKernelGGL((k_lrcheck<true, int32_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL((k_lrcheck<false, int32_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
     }
 }
 

@@ -14,12 +14,13 @@ struct OpHead {
     static __device__ int f(int a, int b) { return (int)(((unsigned)a & 0xffff0000u) + ((unsigned)b & 0xffff0000u)) | max(a & 0xffff, b & 0xffff); }
 };
 
-// Inclusive scan of v[0..W) (int32 in LDS) in place.  Whole workgroup; ends with a barrier.
+// Inclusive scan of v[0..W) (int32 in LDS) in place.  Whole workgroup (any multiple of 64 threads up to 256);
+// ends with a barrier.
 template <typename Op>
 __device__ __forceinline__ void row_scan(int* v, int W, int* wsum)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int CH = (W + 255) >> 8;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nt = blockDim.x;
+    const int CH = (W + nt - 1) / nt;
     const int x0 = tid * CH;
     int run = Op::id();
     for (int k = 0; k < CH; ++k) {
@@ -86,14 +87,14 @@ __device__ __forceinline__ void spk_row_init(const int16_t* d, int* sc, int* wsu
                                              int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                                              int16_t* headmap, int newVal, int maxDiff)
 {
-    for (int x = threadIdx.x; x < W; x += 256) {
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
         const int v = d[x];
         const bool head = v != newVal && !(x > 0 && conn(v, d[x - 1], newVal, maxDiff));
         sc[x] = head ? ((1 << 16) | (x + 1)) : 0;
     }
     __syncthreads();
     row_scan<OpHead>(sc, W, wsum);
-    for (int x = threadIdx.x; x < W; x += 256) {
+    for (int x = threadIdx.x; x < W; x += blockDim.x) {
         const int v = d[x];
         const int h = (sc[x] & 0xffff) - 1;
         headmap[base + x] = (int16_t)h;
