@@ -81,7 +81,7 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
 
 /* Batched stream of independent pairs (BASELINE config 4).  Device-resident variant: frame i
  * of an image lives at base + i*frame_stride, rows `pitch` bytes apart; the work is enqueued on
- * `hip_stream` (a hipStream_t, NULL = the matcher's own stream) and NOT synchronised.  n may
+ * `hip_stream` (a hipStream_t; NULL = the HIP null stream, which is also torch's default stream) and NOT synchronised.  n may
  * exceed max_batch; it is processed in chunks. */
 int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint8_t* d_right,
                            size_t pitch, size_t frame_stride, int width, int height,

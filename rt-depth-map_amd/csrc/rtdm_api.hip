@@ -168,7 +168,7 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     }
     {   // lanes: slices of the workspace (lane 1 starts laneB frames in)
         const char* env = getenv("RTDM_LANES");
-        bm->nlanes = (max_batch >= 2 && !(env && atoi(env) == 1)) ? 2 : 1;
+        bm->nlanes = (max_batch >= 2 && env && atoi(env) == 2) ? 2 : 1;   // opt-in: measured +1 % only, and it blurs per-kernel timings
         bm->laneB = bm->nlanes == 2 ? (max_batch + 1) / 2 : max_batch;
         HIPC(hipEventCreateWithFlags(&bm->evIn, hipEventDisableTiming));
         for (int k = 0; k < bm->nlanes; ++k) {
@@ -350,7 +350,7 @@ int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint
     if (pitch < (size_t)width || disp_pitch < (size_t)width * 2 || (disp_pitch & 1) || (disp_frame_stride & 1))
         return RTDM_ERR_BAD_SIZE;
     HIPC(hipSetDevice(bm->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : bm->stream;
+    hipStream_t s = (hipStream_t)hip_stream;          // NULL = the HIP null stream (what torch's default stream is)
     const bool split = bm->nlanes == 2 && n >= 2;
     if (!split) {
         for (int i0 = 0; i0 < n; i0 += bm->laneB) {
@@ -556,7 +556,7 @@ int rtdm_morph_run_device(rtdm_morph* mf, int n, const uint8_t* d_in, size_t in_
     if (n <= 0 || width <= 0 || height <= 0 || (size_t)width * height > (size_t)mf->W * mf->H) return RTDM_ERR_BAD_SIZE;
     if (in_pitch < (size_t)width || out_pitch < (size_t)width) return RTDM_ERR_BAD_SIZE;
     HIPC(hipSetDevice(mf->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : mf->stream;
+    hipStream_t s = (hipStream_t)hip_stream;          // NULL = the HIP null stream
     for (int i0 = 0; i0 < n; i0 += mf->maxB) {
         const int m = std::min(mf->maxB, n - i0);
         Plane8 in{d_in + (size_t)i0 * in_frame_stride, in_pitch, in_frame_stride};
@@ -669,7 +669,7 @@ int rtdm_sgm_compute_device(rtdm_sgm* sg, int n, const uint8_t* d_left, const ui
     if (n <= 0 || width <= 0 || height <= 0 || width > sg->maxW || height > sg->maxH) return RTDM_ERR_BAD_SIZE;
     if (pitch < (size_t)width || disp_pitch < (size_t)width * 2 || (disp_pitch & 1) || (disp_frame_stride & 1)) return RTDM_ERR_BAD_SIZE;
     HIPC(hipSetDevice(sg->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : sg->stream;
+    hipStream_t s = (hipStream_t)hip_stream;          // NULL = the HIP null stream
     for (int i0 = 0; i0 < n; i0 += sg->maxB) {
         const int m = std::min(sg->maxB, n - i0);
         Plane8 L{d_left + (size_t)i0 * frame_stride, pitch, frame_stride}, R{d_right + (size_t)i0 * frame_stride, pitch, frame_stride};

@@ -276,3 +276,32 @@ def test_sgm_device_batch(pkg, oracle, synth):
     torch.cuda.synchronize()
     for i in range(n):
         assert_same(dD[i].cpu().numpy(), oracle.sgm_compute(L[i], R[i], numDisparities=D))
+
+
+def test_device_api_is_ordered_on_the_callers_stream(pkg, synth):
+    # torch's current stream is the HIP null stream (handle 0): work enqueued by rtdm_bm_compute_device
+    # must be ordered against torch ops issued before and after it WITHOUT an explicit synchronise.
+    import torch
+    sh = load("sharding")
+    W, H, D, N = 640, 480, 64, 12
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.current_stream().cuda_stream
+    left = torch.empty((N, H, W), dtype=torch.uint8, device=dev); right = torch.empty_like(left)
+    pkg.synth_pairs_device(left, right, first_frame=0, numDisparities=D)
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=9, width=W, height=H, max_batch=8)
+    ref = torch.empty((N, H, W), dtype=torch.int16, device=dev)
+    m.compute_device(left, right, ref, st)
+    torch.cuda.synchronize()
+
+    def compute(L, R):
+        out = torch.empty(L.shape, dtype=torch.int16, device=dev)
+        m.compute_device(L.contiguous(), R.contiguous(), out, st)
+        return out                                   # consumed by torch copies right away, no sync
+
+    class Solo:
+        get_world_size = staticmethod(lambda: 1); get_rank = staticmethod(lambda: 0)
+        scatter = staticmethod(lambda t, l, src=0: t.copy_(l[0])); gather = staticmethod(lambda t, l, dst=0: l[0].copy_(t))
+    for chunk in (3, None):
+        out = sh.scatter_compute_gather(Solo, left, right, N, (H, W), compute, dev, chunk=chunk)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
