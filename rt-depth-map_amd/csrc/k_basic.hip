@@ -133,7 +133,17 @@ void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int val
 // the same pass.  With SPK the final row is handed straight to the speckle filter's init step.
 // ---------------------------------------------------------------------------------------------
 // KT = key type: 32-bit keys (cost << 16 | x) when the cost plane is 16-bit, else 64-bit (cost << 32 | x).
-template <bool SPK, typename CT, typename KT>
+// R = rows per workgroup.  With the speckle filter on (SPK) the R checked rows stay in LDS together with their
+// head maps, so the R-1 row pairs inside the block are merged right here (one union per vertical contact
+// segment) and only every R-th pair is left to k_spk_merge.
+static int lr_rows()   // rows per workgroup when the speckle init is fused (RTDM_LR_ROWS = 1 | 2 | 4)
+{
+    static int r = 0;
+    if (!r) { const char* e = getenv("RTDM_LR_ROWS"); r = e ? atoi(e) : 1; if (r != 1 && r != 2 && r != 4) r = 1; }
+    return r;
+}
+
+template <bool SPK, typename CT, typename KT, int R>
 __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, BMGeom g, int maxDiff16,
                                                  int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                                                  int16_t* headmap, int spkDiff)
@@ -141,45 +151,68 @@ __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int KSH = sizeof(KT) * 4;                               // bit position of the cost inside a key
     constexpr KT NONE = (KT)~(KT)0, XMASK = ((KT)1 << KSH) - 1;
+    constexpr int KB = sizeof(KT) > 4 ? 8 : 4;
+    const int W = g.W, INV = g.filtered;
     int* sc = (int*)smem;                                             // W ints: keys first, then scan scratch
     KT* key = (KT*)smem;                                              // (64-bit keys need 2W ints)
-    int16_t* snap = (int16_t*)(smem + (size_t)g.W * (sizeof(KT) > 4 ? 8 : 4));   // W
-    int16_t* fin = snap + g.W;                                        // W (final row)
+    int16_t* snap = (int16_t*)(smem + (size_t)W * KB);                // W
+    int16_t* finb = snap + W;                                         // R x W final rows
+    int16_t* hmb = finb + (size_t)R * W;                              // R x W head maps (SPK only)
     __shared__ int wsum[4];
     const int nt = blockDim.x;
-    const int y = g.vy0 + blockIdx.y;
     const int f = blockIdx.z;
-    int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const CT* crow = cost + ((size_t)f * g.H + y) * g.W;
-    const int W = g.W, INV = g.filtered;
-    for (int x = threadIdx.x; x < W; x += nt) { key[x] = NONE; snap[x] = row[x]; }
-    __syncthreads();
+    const int yb = g.vy0 + blockIdx.y * R;                            // first row of this block
+    const int nr = min(R, g.vy1 - yb);
     const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
-    for (int x = minX1 + threadIdx.x; x < maxX1; x += nt) {
-        const int d = snap[x];
-        if (d == INV) continue;
-        const int x2 = x - ((d + 8) >> 4);
-        if (x2 < 0 || x2 >= W) continue;
-        atomicMin(&key[x2], ((KT)(unsigned)crow[x] << KSH) | (KT)(unsigned)x);
-    }
-    __syncthreads();
-    for (int x = threadIdx.x; x < W; x += nt) {
-        int d = snap[x];
-        bool kill = (x < g.vx0 || x >= g.vx1);
-        if (!kill && d != INV && x >= minX1 && x < maxX1) {
-            const int x0 = x - (d >> 4), x1 = x - ((d + 15) >> 4);
-            bool bad0 = false, bad1 = false;
-            if (x0 >= 0 && x0 < W && key[x0] != NONE) bad0 = abs((int)snap[(unsigned)(key[x0] & XMASK)] - d) > maxDiff16;
-            if (x1 >= 0 && x1 < W && key[x1] != NONE) bad1 = abs((int)snap[(unsigned)(key[x1] & XMASK)] - d) > maxDiff16;
-            kill = bad0 && bad1;
+    for (int r = 0; r < nr; ++r) {
+        const int y = yb + r;
+        int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+        const CT* crow = cost + ((size_t)f * g.H + y) * W;
+        int16_t* fin = finb + (size_t)r * W;
+        for (int x = threadIdx.x; x < W; x += nt) { key[x] = NONE; snap[x] = row[x]; }
+        __syncthreads();
+        for (int x = minX1 + threadIdx.x; x < maxX1; x += nt) {
+            const int d = snap[x];
+            if (d == INV) continue;
+            const int x2 = x - ((d + 8) >> 4);
+            if (x2 < 0 || x2 >= W) continue;
+            atomicMin(&key[x2], ((KT)(unsigned)crow[x] << KSH) | (KT)(unsigned)x);
         }
-        if (kill && d != INV) { row[x] = (int16_t)INV; d = INV; }
-        if (SPK) fin[x] = (int16_t)d;
+        __syncthreads();
+        for (int x = threadIdx.x; x < W; x += nt) {
+            int d = snap[x];
+            bool kill = (x < g.vx0 || x >= g.vx1);
+            if (!kill && d != INV && x >= minX1 && x < maxX1) {
+                const int x0 = x - (d >> 4), x1 = x - ((d + 15) >> 4);
+                bool bad0 = false, bad1 = false;
+                if (x0 >= 0 && x0 < W && key[x0] != NONE) bad0 = abs((int)snap[(unsigned)(key[x0] & XMASK)] - d) > maxDiff16;
+                if (x1 >= 0 && x1 < W && key[x1] != NONE) bad1 = abs((int)snap[(unsigned)(key[x1] & XMASK)] - d) > maxDiff16;
+                kill = bad0 && bad1;
+            }
+            if (kill && d != INV) { row[x] = (int16_t)INV; d = INV; }
+            if (SPK) fin[x] = (int16_t)d;
+        }
+        __syncthreads();
+        if (SPK) {
+            const int base = (f * g.H + y) * W;           // the keys are no longer needed: scan scratch
+            // only the block's first and last row meet rows of other blocks: they alone need the global map
+            spk_row_init(fin, sc, wsum, W, base, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff,
+                         hmb + (size_t)r * W, r == 0 || r == R - 1 || r == nr - 1);
+            __syncthreads();
+        }
     }
     if (SPK) {
-        __syncthreads();
-        const int base = (f * g.H + y) * W;               // the keys are no longer needed: scan scratch
-        spk_row_init(fin, sc, wsum, W, base, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff);
+        // labels written above are plain stores (write-through) followed by barriers; uf_find reads with
+        // agent-scope loads, so they are visible here
+        for (int r = 0; r + 1 < nr; ++r) {
+            const int16_t *d0 = finb + (size_t)r * W, *d1 = d0 + W, *h0 = hmb + (size_t)r * W, *h1 = h0 + W;
+            const int base0 = (f * g.H + yb + r) * W, base1 = base0 + W;
+            for (int x = threadIdx.x; x < W; x += nt) {
+                if (!conn(d0[x], d1[x], INV, spkDiff)) continue;
+                const bool dup = x > 0 && conn(d0[x - 1], d1[x - 1], INV, spkDiff) && h0[x - 1] == h0[x] && h1[x - 1] == h1[x];
+                if (!dup) uf_union(label, base0 + h0[x], base1 + h1[x]);
+            }
+        }
     }
 }
 
@@ -187,28 +220,29 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
                     hipStream_t stream, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                     int16_t* headmap, int spkDiff)
 {
-    // workgroup size is tunable (RTDM_LR_THREADS); 64 / 128 / 256 measured 0.85 / 0.48 / 0.49 ms per 64 frames
-    static int nt = 0;
-    if (!nt) { const char* e = getenv("RTDM_LR_THREADS"); nt = e ? atoi(e) : 256; if (nt != 64 && nt != 128 && nt != 256) nt = 256; }
-    dim3 grid(1, g.vy1 - g.vy0, n), block(nt);
     const int md = disp12MaxDiff * 16;
-    if (g.cost16 && g.W < 65536) {
-        const size_t lds = (size_t)g.W * 8;
-        const uint16_t* c = (const uint16_t*)cost;
-        if (label) hipLaunchKernelGGL((k_lrcheck<true, uint16_t, uint32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        else       hipLaunchKernelGGL((k_lrcheck<false, uint16_t, uint32_t>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-    } else if (g.cost16) {
-        const size_t lds = (size_t)g.W * 12;
-        const uint16_t* c = (const uint16_t*)cost;
-        if (label) hipLaunchKernelGGL((k_lrcheck<true, uint16_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        else       hipLaunchKernelGGL((k_lrcheck<false, uint16_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+    const int nrows = g.vy1 - g.vy0;
+    dim3 block(256);
+    const bool k32 = g.cost16 && g.W < 65536;
+    const size_t kb = k32 ? 4 : 8;
+#define RTDM_LR(SPK, CT, KT, RR)                                                                                     \
+    hipLaunchKernelGGL((k_lrcheck<SPK, CT, KT, RR>), dim3(1, (nrows + RR - 1) / RR, n), block,                        \
+                       (size_t)g.W * (kb + 2 + (SPK ? 4 * RR : 2 * RR)), stream, disp, (const CT*)cost, g, md, label, size, runs, \
+                       rowcnt, headmap, spkDiff)
+    if (label) {
+        const int rr = lr_rows();
+        if (k32) { if (rr == 4) RTDM_LR(true, uint16_t, uint32_t, 4); else if (rr == 2) RTDM_LR(true, uint16_t, uint32_t, 2); else RTDM_LR(true, uint16_t, uint32_t, 1); }
+        else if (g.cost16) { if (rr == 4) RTDM_LR(true, uint16_t, unsigned long long, 4); else if (rr == 2) RTDM_LR(true, uint16_t, unsigned long long, 2); else RTDM_LR(true, uint16_t, unsigned long long, 1); }
+        else { if (rr == 4) RTDM_LR(true, int32_t, unsigned long long, 4); else if (rr == 2) RTDM_LR(true, int32_t, unsigned long long, 2); else RTDM_LR(true, int32_t, unsigned long long, 1); }
     } else {
-        const size_t lds = (size_t)g.W * 12;
-        const int32_t* c = (const int32_t*)cost;
-        if (label) hipLaunchKernelGGL((k_lrcheck<true, int32_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        else       hipLaunchKernelGGL((k_lrcheck<false, int32_t, unsigned long long>), grid, block, lds, stream, disp, c, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        if (k32) RTDM_LR(false, uint16_t, uint32_t, 1);
+        else if (g.cost16) RTDM_LR(false, uint16_t, unsigned long long, 1);
+        else RTDM_LR(false, int32_t, unsigned long long, 1);
     }
+#undef RTDM_LR
 }
+
+int lrcheck_rows_per_block() { return lr_rows(); }
 
 // ---------------------------------------------------------------------------------------------
 // K4 speckle filter (cv::filterSpeckles as called by cv::StereoBM::compute, SURVEY.md Appendix
@@ -248,12 +282,13 @@ struct alignas(16) Short8 { int16_t v[8]; };
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int H,
-                                                   int y_lo, int y_hi, int newVal, int maxDiff)
+                                                   int y_lo, int npairs, int ystep, int newVal, int maxDiff)
 {
+    // pairs (y, y+1) for y = y_lo + k * ystep, k < npairs
     const int nxb = (W + 7) / 8;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nxb * (y_hi - y_lo)) return;
-    const int y = y_lo + idx / nxb, x0 = (idx % nxb) * 8;
+    if (idx >= nxb * npairs) return;
+    const int y = y_lo + (idx / nxb) * ystep, x0 = (idx % nxb) * 8;
     const int f = blockIdx.y;
     const int16_t* d0 = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     const int16_t* d1 = d0 + disp.pitch_e;
@@ -331,22 +366,27 @@ __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t*
 // label/size/runs/headmap: n*W*H elements each; rowcnt: n*H.  If init_done, the rows [y_lo, y_hi) were
 // initialised by k_lrcheck<true> (rowcnt was zeroed before it) and no other row holds a valid pixel.
 void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
-                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int y_lo, int y_hi,
-                    hipStream_t stream)
+                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
+                    int y_lo, int y_hi, hipStream_t stream)
 {
     dim3 block(256);
     if (!init_done) {
-        y_lo = 0; y_hi = H;
+        y_lo = 0; y_hi = H; premerged_rows = 1;
         hipLaunchKernelGGL(k_spk_init, dim3(1, H, n), block, (size_t)W * 6, stream, disp, label, size, runs, rowcnt, headmap,
                            W, H, newVal, maxDiff);
     }
-    const int pairs_hi = min(y_hi, H) - 1;           // pairs (y, y+1) with both rows initialised
-    if (pairs_hi > y_lo) {
+    // row pairs still to merge: (y, y+1), y = first + k*step.  The init pass may already have merged the pairs
+    // inside blocks of premerged_rows rows (k_lrcheck<SPK>); then only the pairs across blocks remain.
+    const int step = premerged_rows > 1 ? premerged_rows : 1;
+    const int first = y_lo + step - 1;
+    const int last = min(y_hi, H) - 2;               // last y with y+1 initialised
+    const int npairs = last >= first ? (last - first) / step + 1 : 0;
+    if (npairs > 0) {
         const int nxb = (W + 7) / 8;
         const bool vec = (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2)) & 15) == 0 && (W & 7) == 0;
-        dim3 grid((nxb * (pairs_hi - y_lo) + 255) / 256, n);
-        if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, H, y_lo, pairs_hi, newVal, maxDiff);
-        else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, H, y_lo, pairs_hi, newVal, maxDiff);
+        dim3 grid((nxb * npairs + 255) / 256, n);
+        if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, H, first, npairs, step, newVal, maxDiff);
+        else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, H, first, npairs, step, newVal, maxDiff);
     }
     const int nrows = n * H;
     hipLaunchKernelGGL(k_spk_count, dim3((nrows + 3) / 4), block, 0, stream, label, size, runs, rowcnt, W, nrows, maxSize);

@@ -325,7 +325,7 @@ static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int
     if (speckle) {
         stage_begin(bm, RTDM_STAGE_SPECKLE, n, s, &ev);
         launch_speckle(disp, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, W, H, n, g.filtered, p.speckleWindowSize,
-                       p.speckleRange, lr, g.vy0, g.vy1, s);
+                       p.speckleRange, lr, lr ? lrcheck_rows_per_block() : 1, g.vy0, g.vy1, s);
         stage_end(bm, s, &ev);
     }
     HIPC(hipGetLastError());

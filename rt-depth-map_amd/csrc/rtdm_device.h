@@ -83,9 +83,12 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b)
 // its own parent with the run length as its size, appends (x | len << 16) to the row's run list and
 // writes the per-pixel head map (x of the run head, int16) that the merge step reads.
 // sc is a W-element int32 scratch array.  Whole workgroup.
+// hm_lds (optional): the head map is also kept in LDS; hm_global = false skips the global head map
+// (rows whose both neighbours are merged by the same workgroup never need it).
 __device__ __forceinline__ void spk_row_init(const int16_t* d, int* sc, int* wsum, int W, int base,
                                              int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
-                                             int16_t* headmap, int newVal, int maxDiff)
+                                             int16_t* headmap, int newVal, int maxDiff,
+                                             int16_t* hm_lds = nullptr, bool hm_global = true)
 {
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         const int v = d[x];
@@ -97,7 +100,8 @@ __device__ __forceinline__ void spk_row_init(const int16_t* d, int* sc, int* wsu
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         const int v = d[x];
         const int h = (sc[x] & 0xffff) - 1;
-        headmap[base + x] = (int16_t)h;
+        if (hm_global) headmap[base + x] = (int16_t)h;
+        if (hm_lds) hm_lds[x] = (int16_t)h;
         if (v == newVal) continue;
         const bool last = (x == W - 1) || !conn(v, d[x + 1], newVal, maxDiff);
         if (!last) continue;

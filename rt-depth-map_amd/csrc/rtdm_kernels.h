@@ -64,10 +64,13 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
 
 // K4: speckle filter (connected components under |a-b| <= maxDiff, size <= maxSize removed).
 // label/size/runs/headmap: n*W*H elements each, rowcnt: n*H.  init_done: rows [y_lo,y_hi) were
-// initialised by launch_lrcheck (rowcnt zeroed beforehand) and every other row is entirely `newVal`.
+// initialised by the caller's row kernel (rowcnt zeroed beforehand) and every other row is entirely
+// `newVal`; premerged_rows > 1: that kernel also merged the row pairs inside blocks of that many rows
+// (lrcheck_rows_per_block() for launch_lrcheck).
 void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
-                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int y_lo, int y_hi,
-                    hipStream_t stream);
+                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
+                    int y_lo, int y_hi, hipStream_t stream);
+int lrcheck_rows_per_block();
 
 // K5: erode / dilate / dilate / erode with the 10x10 ellipse; tmp = n*W*H bytes scratch.
 void launch_morph_open_close(Plane8 in, Plane8W out, uint8_t* tmp0, uint8_t* tmp1, int W, int H,
