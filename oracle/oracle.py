@@ -78,6 +78,9 @@ def lib():
         L.orc_sgm_aggregate.restype = None
         L.orc_sgm_select.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i16p, C.c_size_t]
         L.orc_sgm_select.restype = None
+        L.orc_depth_stats.argtypes = [i16p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, C.c_size_t,
+                                      C.POINTER(C.c_int), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_depth_stats.restype = C.c_int
         _lib = L
     return _lib
 
@@ -207,3 +210,18 @@ def sgm_stages(left, right, **kw):
     L.orc_sgm_block_cost(_p(pix, C.c_uint16), W1, H, D, p.blockSize, _p(Cc, C.c_uint16))
     L.orc_sgm_aggregate(_p(Cc, C.c_uint16), W1, H, D, p.P1, p.P2, _p(S, C.c_uint16))
     return pix, Cc, S
+
+
+def depth_stats(disp16, Q, mask, regions, calibration_unit=25.0):
+    """disp16: int16 HxW (x16); Q: 4x4; mask: uint8 HxW; regions: list of (x,y,w,h) -> (mean_cm[n], counts[n])."""
+    disp16 = np.ascontiguousarray(disp16, np.int16); mask = np.ascontiguousarray(mask, np.uint8)
+    H, W = disp16.shape
+    q = np.ascontiguousarray(Q, np.float64).reshape(16)
+    reg = np.ascontiguousarray(regions, np.int32).reshape(-1, 4)
+    n = len(reg)
+    mean = np.zeros(n, np.float64); cnt = np.zeros(n, np.int32)
+    rc = lib().orc_depth_stats(_p(disp16, C.c_int16), W, W, H, _p(q, C.c_double), _p(mask, C.c_uint8), W,
+                               _p(reg, C.c_int), n, calibration_unit, _p(mean, C.c_double), _p(cnt, C.c_int))
+    if rc != 0:
+        raise ValueError("orc_depth_stats failed: %d" % rc)
+    return mean, cnt

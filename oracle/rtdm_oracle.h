@@ -113,6 +113,13 @@ void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int unique
 int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep,
                     int W, int H, int16_t* disp, size_t dstep_bytes);
 
+/* ---- depth statistics after the matcher (defined in depth_oracle.c) ---------
+ * disp16: the matcher's x16 fixed-point output.  regions: n x (x, y, width, height) inside the image.
+ * mean_cm[i] = mean Z over the valid masked pixels of region i * calibration_unit / 10 (0 if none). */
+int orc_depth_stats(const int16_t* disp16, size_t dstep_elems, int W, int H, const double Q[16],
+                    const uint8_t* mask, size_t mstep, const int* regions, int n,
+                    double calibration_unit, double* mean_cm, int* counts);
+
 #ifdef __cplusplus
 }
 #endif

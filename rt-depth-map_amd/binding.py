@@ -22,6 +22,10 @@ class RtdmError(RuntimeError):
         super().__init__("%s failed: %s (%d) %s" % (where, STATUS.get(status, "?"), status, detail))
 
 
+class Region(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("x", "y", "width", "height")]
+
+
 class SGMParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("blockSize", "minDisparity", "numDisparities", "P1", "P2", "uniquenessRatio",
                                        "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
@@ -74,6 +78,10 @@ def lib():
         "rtdm_sgm_destroy": (None, [vp]),
         "rtdm_sgm_compute": (C.c_int, [vp, u8p, sz, u8p, sz, C.c_int, C.c_int, i16p, sz]),
         "rtdm_sgm_compute_device": (C.c_int, [vp, C.c_int, u8p, u8p, sz, sz, C.c_int, C.c_int, i16p, sz, sz, vp]),
+        "rtdm_bm_compute_depth": (C.c_int, [vp, u8p, sz, u8p, sz, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, sz,
+                                            C.POINTER(Region), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), i16p, sz]),
+        "rtdm_depth_stats_device": (C.c_int, [C.c_int, i16p, sz, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, sz,
+                                              C.POINTER(Region), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), vp]),
         "rtdm_synth_pairs_device": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p,
                                               sz, sz, C.c_int, vp]),
     }
@@ -90,7 +98,7 @@ EXPORTS = ("rtdm_strerror rtdm_last_hip_error rtdm_abi_version rtdm_device_count
            "rtdm_bm_get_stage_time rtdm_bm_reset_stage_times rtdm_bm_search_variant rtdm_morph_create "
            "rtdm_morph_destroy rtdm_morph_in_buffer rtdm_morph_out_buffer rtdm_morph_run "
            "rtdm_morph_run_device rtdm_synth_pairs_device rtdm_sgm_default_params rtdm_sgm_create rtdm_sgm_destroy "
-           "rtdm_sgm_compute rtdm_sgm_compute_device").split()
+           "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_bm_compute_depth rtdm_depth_stats_device").split()
 
 
 def check(status, where):

@@ -54,6 +54,8 @@ struct rtdm_bm {
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
     int16_t* dHead;
+    uint8_t* dMask;                // staging for rtdm_bm_compute_depth: mask plane + reduction scratch
+    void* dDepth;
     uint8_t* hStage;               // page-locked staging for the single-frame host entry point
     size_t hStageBytes;
     bool profiling;
@@ -158,7 +160,9 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dSize, px * sizeof(int32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dRuns, px * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dHead, px * sizeof(int16_t));
-    bm->hStageBytes = 2 * bm->ppitch * (size_t)max_height + (size_t)max_width * max_height * sizeof(int16_t);
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dMask, (size_t)max_width * max_height);
+    if (e == hipSuccess) e = hipMalloc(&bm->dDepth, depth_scratch_bytes(RTDM_MAX_REGIONS, max_height));
+    bm->hStageBytes = 2 * bm->ppitch * (size_t)max_height + (size_t)max_width * max_height * (sizeof(int16_t) + 1) + 1024;
     if (e == hipSuccess) e = hipHostMalloc((void**)&bm->hStage, bm->hStageBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dRowCnt, (size_t)max_batch * max_height * sizeof(int32_t));
     if (e != hipSuccess) {
@@ -197,7 +201,7 @@ void rtdm_bm_destroy(rtdm_bm* bm)
     }
     if (bm->evIn) (void)hipEventDestroy(bm->evIn);
     for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead};
+    void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead, bm->dMask, bm->dDepth};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (bm->hStage) (void)hipHostFree(bm->hStage);
     if (bm->stream) (void)hipStreamDestroy(bm->stream);
@@ -581,6 +585,88 @@ int rtdm_morph_run(rtdm_morph* mf, const uint8_t* in, size_t in_pitch, uint8_t* 
     if (rc) return rc;
     HIPC(hipMemcpy2DAsync(out, out_pitch, mf->dOut, width, width, height, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    return RTDM_OK;
+}
+
+// ---- the step after the matcher ---------------------------------------------------------------
+static int check_regions(const rtdm_region* regions, int n, int W, int H, int* flat, int* maxh)
+{
+    if (n < 0 || n > RTDM_MAX_REGIONS || (n > 0 && !regions)) return RTDM_ERR_BAD_SIZE;
+    *maxh = 1;
+    for (int i = 0; i < n; ++i) {
+        const rtdm_region& r = regions[i];
+        if (r.x < 0 || r.y < 0 || r.width < 0 || r.height < 0 || r.x + r.width > W || r.y + r.height > H) return RTDM_ERR_BAD_SIZE;
+        flat[4 * i] = r.x; flat[4 * i + 1] = r.y; flat[4 * i + 2] = r.width; flat[4 * i + 3] = r.height;
+        *maxh = std::max(*maxh, r.height);
+    }
+    return RTDM_OK;
+}
+
+int rtdm_depth_stats_device(int device, const int16_t* d_disp, size_t disp_pitch, int width, int height, const double* Q,
+                            const uint8_t* d_mask, size_t mask_pitch, const rtdm_region* regions, int nregions,
+                            double calibration_unit, double* mean_cm, int* counts, void* hip_stream)
+{
+    if (!d_disp || !Q || !d_mask || !mean_cm || !counts) return RTDM_ERR_NULL;
+    if (width <= 0 || height <= 0 || disp_pitch < (size_t)width * 2 || (disp_pitch & 1) || mask_pitch < (size_t)width) return RTDM_ERR_BAD_SIZE;
+    int flat[4 * RTDM_MAX_REGIONS], maxh = 1;
+    int rc = check_regions(regions, nregions, width, height, flat, &maxh);
+    if (rc) return rc;
+    rc = use_device(device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)hip_stream;
+    void* scratch = nullptr;
+    HIPC(hipMalloc(&scratch, depth_scratch_bytes(std::max(nregions, 1), maxh)));
+    DepthQ q; std::copy(Q, Q + 16, q.q);
+    launch_depth_stats(d_disp, disp_pitch / 2, width, height, q, d_mask, mask_pitch, flat, nregions, maxh, calibration_unit,
+                       scratch, mean_cm, counts, s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(scratch);
+    HIPC(e);
+    return RTDM_OK;
+}
+
+int rtdm_bm_compute_depth(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const uint8_t* right, size_t right_pitch,
+                          int width, int height, const double* Q, const uint8_t* mask, size_t mask_pitch,
+                          const rtdm_region* regions, int nregions, double calibration_unit,
+                          double* mean_cm, int* counts, int16_t* disp, size_t disp_pitch)
+{
+    if (!bm || !left || !right || !Q || !mask || !mean_cm || !counts) return RTDM_ERR_NULL;
+    int rc = check_frame(bm, width, height);
+    if (rc) return rc;
+    if (left_pitch < (size_t)width || right_pitch < (size_t)width || mask_pitch < (size_t)width) return RTDM_ERR_BAD_SIZE;
+    if (disp && disp_pitch < (size_t)width * 2) return RTDM_ERR_BAD_SIZE;
+    int flat[4 * RTDM_MAX_REGIONS], maxh = 1;
+    rc = check_regions(regions, nregions, width, height, flat, &maxh);
+    if (rc) return rc;
+    HIPC(hipSetDevice(bm->device));
+    hipStream_t s = bm->stream;
+    const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
+    uint8_t* hL = bm->hStage;
+    uint8_t* hR = hL + dframe;
+    int16_t* hD = (int16_t*)(bm->hStage + 2 * bm->ppitch * (size_t)bm->maxH);
+    uint8_t* hM = (uint8_t*)(hD + (size_t)bm->maxW * bm->maxH);
+    for (int y = 0; y < height; ++y) {
+        memcpy(hL + (size_t)y * dpitch, left + (size_t)y * left_pitch, (size_t)width);
+        memcpy(hR + (size_t)y * dpitch, right + (size_t)y * right_pitch, (size_t)width);
+        memcpy(hM + (size_t)y * width, mask + (size_t)y * mask_pitch, (size_t)width);
+    }
+    HIPC(hipMemcpyAsync(bm->dInL, hL, dframe, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(bm->dInR, hR, dframe, hipMemcpyHostToDevice, s));
+    HIPC(hipMemcpyAsync(bm->dMask, hM, (size_t)width * height, hipMemcpyHostToDevice, s));
+    Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
+    Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
+    rc = run_chunk(bm, bm->lane[0], 1, L, R, width, height, O, s);
+    if (rc) return rc;
+    DepthQ q; std::copy(Q, Q + 16, q.q);
+    launch_depth_stats(bm->dOut, (size_t)width, width, height, q, bm->dMask, (size_t)width, flat, nregions, bm->maxH,
+                       calibration_unit, bm->dDepth, mean_cm, counts, s);
+    if (disp) HIPC(hipMemcpyAsync(hD, bm->dOut, (size_t)width * height * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s));
+    if (disp)
+        for (int y = 0; y < height; ++y)
+            memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * width, (size_t)width * sizeof(int16_t));
     return RTDM_OK;
 }
 

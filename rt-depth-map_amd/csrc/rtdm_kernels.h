@@ -87,6 +87,15 @@ struct SGMBuffers {
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
                 int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int n, hipStream_t stream);
 
+// Depth statistics after the matcher (estimator.cpp:75-77, 206-263).  q = the 4x4 reprojection matrix Q, row major.
+struct DepthQ { double q[16]; };
+size_t depth_scratch_bytes(int max_regions, int maxH);
+// h_regions: n x (x, y, w, h) on the host, inside the image; rows of a region are summed by one workgroup each
+// (maxH >= the tallest region).  Results arrive in h_mean / h_counts after the stream is synchronised.
+void launch_depth_stats(const int16_t* disp, size_t pitch_e, int W, int H, const DepthQ& q, const uint8_t* mask, size_t mpitch,
+                        const int* h_regions, int n, int maxH, double unit, void* scratch, double* h_mean, int* h_counts,
+                        hipStream_t stream);
+
 // Synthetic stream generator (bit-identical to synth.py).
 void launch_synth(uint64_t seed, int first_frame, int n, int W, int H, int D, Plane8W L, Plane8W R,
                   void* param_scratch, hipStream_t stream);

@@ -46,6 +46,18 @@ int HIPMatcherCore::computeBatch(int n, const uint8_t* left, const uint8_t* righ
     return status_;
 }
 
+int HIPMatcherCore::computeDepth(const uint8_t* left, size_t leftStep, const uint8_t* right, size_t rightStep, int rows,
+                                 int cols, const double* Q, const uint8_t* mask, size_t maskStep, const Rect* regions,
+                                 int nregions, double calibrationUnit, double* meanCm, int* counts, int16_t* out, size_t outStep)
+{
+    if (!bm_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    static_assert(sizeof(Rect) == sizeof(rtdm_region), "Rect and rtdm_region share their layout");
+    status_ = rtdm_bm_compute_depth(bm_, left, leftStep, right, rightStep, cols, rows, Q, mask, maskStep,
+                                    reinterpret_cast<const rtdm_region*>(regions), nregions, calibrationUnit, meanCm, counts,
+                                    out, outStep);
+    return status_;
+}
+
 HIPMorphCore::HIPMorphCore(int w, int h, int bpp, int device) : width_(w), height_(h), bpp_(bpp)
 {
     status_ = (bpp == 8) ? rtdm_morph_create(w, h, 1, device, &mf_) : RTDM_ERR_UNSUPPORTED;

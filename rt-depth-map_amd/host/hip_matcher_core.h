@@ -41,6 +41,13 @@ public:
     int computeBatch(int n, const uint8_t* left, const uint8_t* right, size_t step, size_t frameStride,
                      int rows, int cols, int16_t* out, size_t outStep, size_t outFrameStride);
 
+    // The caller's next three lines in one call (estimator.cpp:75-77): left_disp /= 16., reprojectImageTo3D with
+    // Q (row-major 4x4), calc_depth over `regions` under `mask`; the disparity stays on the device unless `out`
+    // is given.  meanCm[i] = mean Z * calibrationUnit / 10, counts[i] = pixels that entered the mean.
+    int computeDepth(const uint8_t* left, size_t leftStep, const uint8_t* right, size_t rightStep, int rows, int cols,
+                     const double* Q, const uint8_t* mask, size_t maskStep, const Rect* regions, int nregions,
+                     double calibrationUnit, double* meanCm, int* counts, int16_t* out = nullptr, size_t outStep = 0);
+
     int status() const { return status_; }           // result of construction / last call
     const char* statusText() const { return rtdm_strerror(status_); }
     int filteredValue() const { return (params_.minDisparity - 1) * 16; }

@@ -56,6 +56,23 @@ class HIPMatcher:
                                         right.strides[0], W, H, disp.ctypes.data, W * 2), "rtdm_bm_compute")
         return disp
 
+    def compute_depth(self, left, right, Q, mask, regions, calibration_unit=25.0, want_disp=False):
+        """estimator.cpp:56,75-77 in one call: match, /= 16, reproject with Q, mean Z per region under `mask`.
+        Returns (mean_cm[n], counts[n]) and, if want_disp, the x16 disparity map as well."""
+        assert left.dtype == np.uint8 and right.dtype == np.uint8 and mask.dtype == np.uint8 and left.shape == right.shape == mask.shape
+        H, W = left.shape
+        q = np.ascontiguousarray(Q, np.float64).reshape(16)
+        n = len(regions)
+        reg = (B.Region * max(n, 1))(*[B.Region(*[int(v) for v in r]) for r in regions])
+        mean = np.zeros(n, np.float64); cnt = np.zeros(n, np.int32)
+        disp = np.empty((H, W), np.int16) if want_disp else None
+        B.check(B.lib().rtdm_bm_compute_depth(
+            self._h, left.ctypes.data, left.strides[0], right.ctypes.data, right.strides[0], W, H,
+            q.ctypes.data_as(C.POINTER(C.c_double)), mask.ctypes.data, mask.strides[0], reg, n, calibration_unit,
+            mean.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_int)),
+            disp.ctypes.data if want_disp else None, W * 2), "rtdm_bm_compute_depth")
+        return (mean, cnt, disp) if want_disp else (mean, cnt)
+
     def compute_batch(self, left, right):
         """left/right: uint8 [n, H, W] C-contiguous host arrays -> int16 [n, H, W]."""
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
@@ -189,6 +206,20 @@ class HIPMorphologicalFilter:
         n, H, W = d_in.shape
         B.check(B.lib().rtdm_morph_run_device(self._h, n, d_in.data_ptr(), W, W * H, d_out.data_ptr(), W, W * H,
                                               W, H, stream), "rtdm_morph_run_device")
+
+
+def depth_stats_device(d_disp, Q, d_mask, regions, calibration_unit=25.0, device=0, stream=None):
+    """torch CUDA tensors: int16 [H,W] x16 disparity, uint8 [H,W] mask -> (mean_cm[n], counts[n]); synchronous."""
+    H, W = d_disp.shape
+    q = np.ascontiguousarray(Q, np.float64).reshape(16)
+    n = len(regions)
+    reg = (B.Region * max(n, 1))(*[B.Region(*[int(v) for v in r]) for r in regions])
+    mean = np.zeros(n, np.float64); cnt = np.zeros(n, np.int32)
+    B.check(B.lib().rtdm_depth_stats_device(device, d_disp.data_ptr(), W * 2, W, H, q.ctypes.data_as(C.POINTER(C.c_double)),
+                                            d_mask.data_ptr(), W, reg, n, calibration_unit,
+                                            mean.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_int)),
+                                            stream), "rtdm_depth_stats_device")
+    return mean, cnt
 
 
 def synth_pairs_device(d_left, d_right, first_frame, numDisparities, seed=None, device=0, stream=None):

@@ -300,3 +300,25 @@ def sgm(L, R, numDisparities=32, minDisparity=0, blockSize=5, P1=600, P2=2400, u
     if speckleWindowSize > 0 and speckleRange >= 0:
         out = speckle(out.astype(np.int16), INV, speckleWindowSize, 16 * speckleRange).astype(np.int64)
     return out.astype(np.int16)
+
+
+# ---- depth statistics after the matcher (estimator.cpp:75-77, 206-263), numpy version --------------------
+def depth_stats(disp16, Q, mask, regions, unit=25.0):
+    d = np.rint(disp16.astype(np.float64) / 16.0).astype(np.int64)       # numpy rint = ties to even
+    H, W = d.shape
+    y, x = np.mgrid[0:H, 0:W].astype(np.float64)
+    Q = np.asarray(Q, np.float64).reshape(4, 4)
+    Zh = Q[2, 0] * x + Q[2, 1] * y + Q[2, 2] * d + Q[2, 3]
+    Wh = Q[3, 0] * x + Q[3, 1] * y + Q[3, 2] * d + Q[3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        z = (Zh / Wh).astype(np.float32)
+    z[d == d.min()] = np.float32(10000.0)
+    zz = z.astype(np.float64)
+    ok = ~(np.abs(zz - 10000.0) < np.finfo(np.float32).eps) & ~(np.abs(zz) > 10000.0) & (mask != 0)
+    means, counts = [], []
+    for (rx, ry, rw, rh) in regions:
+        sel = ok[ry:ry + rh, rx:rx + rw]
+        c = int(sel.sum())
+        counts.append(c)
+        means.append(float(zz[ry:ry + rh, rx:rx + rw][sel].sum() / c * unit / 10.0) if c else 0.0)
+    return np.array(means), np.array(counts)

@@ -305,3 +305,39 @@ def test_device_api_is_ordered_on_the_callers_stream(pkg, synth):
         out = sh.scatter_compute_gather(Solo, left, right, N, (H, W), compute, dev, chunk=chunk)
         torch.cuda.synchronize()
         assert torch.equal(out, ref)
+
+
+# ---- next row: /= 16 + reprojectImageTo3D + calc_depth on the device ---------
+# Floating point: Z is a float from a double quotient, the mean a double sum.  The device sums in a
+# different (fixed) order than the oracle, hence a tolerance: 1e-9 relative on the mean, counts exact.
+Q_TEST = np.array([[1, 0, 0, -640.3], [0, 1, 0, -360.8], [0, 0, 0, 700.25], [0, 0, 1 / 12.0, 0.0]])
+
+
+def test_compute_depth_matches_oracle(pkg, oracle, synth):
+    W, H, D = 1280, 720, 64
+    L, R = synth.make_pair(synth.STREAM_SEED + 77, W, H, D)
+    mask = ((L > 100) * 255).astype(np.uint8)
+    regions = [(200, 150, 300, 220), (0, 0, W, H), (900, 400, 120, 200), (10, 10, 1, 1), (600, 700, 80, 0)]
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=9, width=W, height=H)
+    mean, cnt, disp = m.compute_depth(L, R, Q_TEST, mask, regions, calibration_unit=25.0, want_disp=True)
+    want_disp = oracle.bm_compute(L, R, numDisparities=D, blockSize=9, nthreads=8)
+    assert_same(disp, want_disp)
+    wm, wc = oracle.depth_stats(want_disp, Q_TEST, mask, regions, 25.0)
+    assert np.array_equal(cnt, wc) and wc[1] > 100000
+    assert np.allclose(mean, wm, rtol=1e-9, atol=0)
+    mean2, cnt2 = m.compute_depth(L, R, Q_TEST, mask, regions)            # reproducible run to run, bit for bit
+    assert np.array_equal(mean, mean2) and np.array_equal(cnt, cnt2)
+    with pytest.raises(pkg.binding.RtdmError):
+        m.compute_depth(L, R, Q_TEST, mask, [(1200, 700, 100, 100)])
+
+
+def test_depth_stats_device_matches_oracle(pkg, oracle, synth):
+    import torch
+    L, R = synth.make_pair(synth.STREAM_SEED + 78, 320, 240, 32)
+    d = oracle.bm_compute(L, R, numDisparities=32, blockSize=9)
+    mask = ((L > 110) * 255).astype(np.uint8)
+    Qs = np.array([[1, 0, 0, -160.5], [0, 1, 0, -120.25], [0, 0, 0, 310.7], [0, 0, 1 / 2.4, 0.0]])
+    regions = [(40, 30, 100, 80), (0, 0, 320, 240), (317, 200, 3, 40)]
+    mean, cnt = pkg.depth_stats_device(torch.from_numpy(d).cuda(), Qs, torch.from_numpy(mask).cuda(), regions)
+    wm, wc = oracle.depth_stats(d, Qs, mask, regions)
+    assert np.array_equal(cnt, wc) and np.allclose(mean, wm, rtol=1e-9, atol=0)
