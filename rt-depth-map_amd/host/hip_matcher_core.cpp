@@ -58,6 +58,25 @@ int HIPMatcherCore::computeDepth(const uint8_t* left, size_t leftStep, const uin
     return status_;
 }
 
+HIPSGMCore::HIPSGMCore(int blockSize, int minDisparity, int numOfDisparities, int uniquenessRatio, int speckleWindowSize,
+                       int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device)
+{
+    rtdm_sgm_params p;
+    rtdm_sgm_default_params(&p, numOfDisparities, blockSize);     // P1 = 8*3*5*5, P2 = 32*3*5*5 (sgbm-sw.cpp:17-18)
+    p.minDisparity = minDisparity; p.uniquenessRatio = uniquenessRatio; p.speckleWindowSize = speckleWindowSize;
+    p.speckleRange = speckleRange; p.disp12MaxDiff = disp12MaxDiff;
+    status_ = rtdm_sgm_create(&p, maxWidth, maxHeight, 1, device, &sg_);
+    if (status_ != RTDM_OK) std::fprintf(stderr, "HIPSemiGlobalMatcher: %s\n", rtdm_strerror(status_));
+}
+HIPSGMCore::~HIPSGMCore() { rtdm_sgm_destroy(sg_); }
+int HIPSGMCore::compute(const uint8_t* left, size_t leftStep, const uint8_t* right, size_t rightStep, int rows, int cols,
+                        int16_t* out, size_t outStep)
+{
+    if (!sg_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    status_ = rtdm_sgm_compute(sg_, left, leftStep, right, rightStep, cols, rows, out, outStep);
+    return status_;
+}
+
 HIPMorphCore::HIPMorphCore(int w, int h, int bpp, int device) : width_(w), height_(h), bpp_(bpp)
 {
     status_ = (bpp == 8) ? rtdm_morph_create(w, h, 1, device, &mf_) : RTDM_ERR_UNSUPPORTED;

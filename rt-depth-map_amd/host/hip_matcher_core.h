@@ -59,6 +59,25 @@ private:
     int status_ = RTDM_OK;
 };
 
+// SWSemiGlobalMatcher counterpart (/root/reference/include/stereo-matcher/sgbm-sw.h:24-37): the same seven
+// constructor arguments in the same order plus the frame size; P1 = 600 and P2 = 2400 as sgbm-sw.cpp:17-18
+// hard-codes them; setROI1/2 are no-ops there too.  8-path aggregation (BASELINE config 5).
+class HIPSGMCore {
+public:
+    HIPSGMCore(int blockSize, int minDisparity, int numOfDisparities, int uniquenessRatio, int speckleWindowSize,
+               int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device = 0);
+    ~HIPSGMCore();
+    HIPSGMCore(const HIPSGMCore&) = delete;
+    HIPSGMCore& operator=(const HIPSGMCore&) = delete;
+    int compute(const uint8_t* left, size_t leftStep, const uint8_t* right, size_t rightStep,
+                int rows, int cols, int16_t* out, size_t outStep);
+    int status() const { return status_; }
+
+private:
+    rtdm_sgm* sg_ = nullptr;
+    int status_ = RTDM_OK;
+};
+
 // VideoFilterDevice counterpart (/root/reference/include/filter/filter.h:13-37,
 // /root/reference/filter/mf-sw.cpp:10-28): owns the frame buffers it hands out.
 class HIPMorphCore {
