@@ -34,7 +34,8 @@ def test_adapters_match_reference_interfaces(tmp_path):
     (inc / "filter").mkdir()
     shutil.copy(os.path.join(HOST, "bm-hip.h"), inc / "stereo-matcher" / "bm-hip.h")
     shutil.copy(os.path.join(HOST, "mf-hip.h"), inc / "filter" / "mf-hip.h")
-    for src in ("bm-hip.cpp", "mf-hip.cpp"):
+    shutil.copy(os.path.join(HOST, "sgbm-hip.h"), inc / "stereo-matcher" / "sgbm-hip.h")
+    for src in ("bm-hip.cpp", "mf-hip.cpp", "sgbm-hip.cpp"):
         cmd = ["g++", "-std=c++11", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "shims"),
                "-I", str(inc), "-I", os.path.join(REF, "include"), "-I", HOST, os.path.join(HOST, src)]
         r = subprocess.run(cmd, capture_output=True, text=True)
