@@ -1,0 +1,84 @@
+"""Randomised parity sweep on the GPU: every kernel variant (fast quad-SAD instantiations, border columns,
+generic LDS kernel in both tile widths and both accumulator types, left-right check with 32/64-bit keys,
+speckle filter, SGM-8) is driven through the C ABI with random sizes / parameters / ROIs and compared
+bit-for-bit with the oracle.  Seeds are fixed, so a failure is reproducible from its parameter string."""
+import numpy as np
+import pytest
+
+from conftest import load
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available()
+    return load()
+
+
+def _case(rng):
+    D = int(rng.choice([16, 32, 48, 64, 96, 128, 192, 256], p=[.15, .2, .05, .25, .05, .15, .1, .05]))
+    w = int(rng.choice([5, 7, 9, 11, 13, 15, 21, 25]))
+    minD = int(rng.choice([0, 0, 0, 0, 3, -7, -20]))
+    W = int(rng.integers(D + abs(minD) + w + 20, D + abs(minD) + w + 260))
+    H = int(rng.integers(w + 3, w + 70))
+    kw = dict(numDisparities=D, blockSize=w, minDisparity=minD,
+              preFilterCap=int(rng.choice([31, 31, 31, 15, 63, 5])),
+              textureThreshold=int(rng.choice([10, 0, 40, 200])),
+              uniquenessRatio=int(rng.choice([10, 0, 15, 50])),
+              speckleWindowSize=int(rng.choice([100, 0, 20, 400])),
+              speckleRange=int(rng.choice([32, 4, 0, 64])),
+              disp12MaxDiff=int(rng.choice([1, -1, 0, 3])))
+    roi1 = roi2 = None
+    if rng.random() < 0.35:
+        x0, y0 = int(rng.integers(0, W // 2)), int(rng.integers(0, H // 2))
+        roi1 = (x0, y0, int(rng.integers(1, W - x0 + 1)), int(rng.integers(1, H - y0 + 1)))
+    if rng.random() < 0.15:
+        x0, y0 = int(rng.integers(0, W // 3)), int(rng.integers(0, H // 3))
+        roi2 = (x0, y0, int(rng.integers(W // 2, W - x0 + 1)), int(rng.integers(H // 2, H - y0 + 1)))
+    return W, H, kw, roi1, roi2
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_block_matching_configuration(pkg, oracle, synth, seed):
+    rng = np.random.default_rng(1000 + seed)
+    W, H, kw, roi1, roi2 = _case(rng)
+    L, R = synth.make_pair(synth.STREAM_SEED + 5000 + seed, W, H, kw["numDisparities"])
+    if seed % 5 == 0:                       # pitched, odd-aligned views like estimator.cpp:33,36
+        pad = np.zeros((H + 3, W + 37), np.uint8)
+        pl, pr = pad.copy(), pad.copy()
+        pl[2:2 + H, 5:5 + W] = L; pr[2:2 + H, 5:5 + W] = R
+        L, R = pl[2:2 + H, 5:5 + W], pr[2:2 + H, 5:5 + W]
+    want = oracle.bm_compute(L, R, roi1=roi1, roi2=roi2, **kw)
+    m = pkg.HIPMatcher(numOfDisparities=kw["numDisparities"], blockSize=kw["blockSize"], minDisparity=kw["minDisparity"],
+                       preFilterCap=kw["preFilterCap"], textureThreshold=kw["textureThreshold"],
+                       uniquenessRatio=kw["uniquenessRatio"], speckleWindowSize=kw["speckleWindowSize"],
+                       speckleRange=kw["speckleRange"], disp12MaxDiff=kw["disp12MaxDiff"], width=W, height=H)
+    if roi1: m.setROI1(roi1)
+    if roi2: m.setROI2(roi2)
+    got = m.compute(L, R)
+    variant = m.search_variant
+    m.close()
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("seed %d %dx%d %s roi1=%s roi2=%s variant=%s: %d pixels differ, first (y,x)=%s got %d want %d" % (
+            seed, W, H, kw, roi1, roi2, variant, len(bad), tuple(bad[0]), got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_sgm_configuration(pkg, oracle, synth, seed):
+    rng = np.random.default_rng(2000 + seed)
+    D = int(rng.choice([16, 32, 64, 128, 192]))
+    bs = int(rng.choice([1, 3, 5, 7]))
+    minD = int(rng.choice([0, 0, 2, -3]))
+    W, H = int(rng.integers(D + 30, D + 150)), int(rng.integers(12, 60))
+    kw = dict(blockSize=bs, minDisparity=minD, uniquenessRatio=int(rng.choice([10, 0, 30])),
+              speckleWindowSize=int(rng.choice([100, 0, 15])), speckleRange=int(rng.choice([32, 1, 2])),
+              disp12MaxDiff=int(rng.choice([1, -1, 0])), P1=int(rng.choice([600, 8, 100])), P2=int(rng.choice([2400, 700, 3000])))
+    L, R = synth.make_pair(synth.STREAM_SEED + 7000 + seed, W, H, D)
+    want = oracle.sgm_compute(L, R, numDisparities=D, **kw)
+    m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, **kw)
+    got = m.compute(L, R)
+    m.close()
+    assert np.array_equal(got, want), (seed, W, H, D, kw, int((got != want).sum()))
