@@ -371,25 +371,30 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles + extra, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg, bg);
 }
 
+// Instantiations: every (D, pieces) with D in {16,32,48,64,96,128,192,256} and 2..4 pieces (w = 5..15), plus
+// 5 and 6 pieces (w = 17..21) for D in {32,64,128}.  Anything else runs the generic kernel.
+#define RTDM_FAST_TABLE(X)                                                                               \
+    X(16, 2) X(16, 3) X(16, 4) X(32, 2) X(32, 3) X(32, 4) X(32, 5) X(32, 6) X(48, 2) X(48, 3) X(48, 4)    \
+    X(64, 2) X(64, 3) X(64, 4) X(64, 5) X(64, 6) X(96, 2) X(96, 3) X(96, 4)                               \
+    X(128, 2) X(128, 3) X(128, 4) X(128, 5) X(128, 6) X(192, 2) X(192, 3) X(192, 4) X(256, 2) X(256, 3) X(256, 4)
+
 bool fast_search_supported(const BMGeom& g)
 {
     if (2L * g.cap * g.w * g.w > 32766) return false;       // packed u16 sums + the T+1 <= 32767 argument
     if (!fast_range(g, nullptr, nullptr)) return false;
     const int np = fast_np(g);
-    if (g.D == 64 && np == 3) return true;
-    if (g.D == 32 && np == 2) return true;
-    if (g.D == 128 && np == 3) return true;
-    if (g.D == 192 && np == 4) return true;
+#define X(DD, PP) if (g.D == DD && np == PP) return true;
+    RTDM_FAST_TABLE(X)
+#undef X
     return false;
 }
 
 void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, bool fuse_border)
 {
     const int np = fast_np(g);
-    if (g.D == 64 && np == 3) launch_one<64, 3>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
-    else if (g.D == 32 && np == 2) launch_one<32, 2>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
-    else if (g.D == 128 && np == 3) launch_one<128, 3>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
-    else if (g.D == 192 && np == 4) launch_one<192, 4>(Lp, Rp, disp, cost, g, n, stream, fuse_border);
+#define X(DD, PP) if (g.D == DD && np == PP) { launch_one<DD, PP>(Lp, Rp, disp, cost, g, n, stream, fuse_border); return; }
+    RTDM_FAST_TABLE(X)
+#undef X
 }
 
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1)

@@ -82,3 +82,21 @@ def test_random_sgm_configuration(pkg, oracle, synth, seed):
     got = m.compute(L, R)
     m.close()
     assert np.array_equal(got, want), (seed, W, H, D, kw, int((got != want).sum()))
+
+
+FAST_TABLE = [(D, np_) for D in (16, 32, 48, 64, 96, 128, 192, 256) for np_ in (2, 3, 4)] + \
+             [(D, np_) for D in (32, 64, 128) for np_ in (5, 6)]
+
+
+@pytest.mark.parametrize("D,pieces", FAST_TABLE)
+def test_every_fast_instantiation(pkg, oracle, synth, D, pieces):
+    # one window size per instantiation (pieces = ceil(w / 4)), alternating the 1- and 3-byte tails
+    w = 4 * (pieces - 1) + (1 if (D // 16 + pieces) % 2 else 3)
+    W, H = D + 4 * w + 150, w + 37
+    L, R = synth.make_pair(synth.STREAM_SEED + 9000 + D + pieces, W, H, D)
+    kw = dict(numDisparities=D, blockSize=w, preFilterCap=31 if 62 * w * w <= 32766 else 15)
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, preFilterCap=kw["preFilterCap"], width=W, height=H)
+    got = m.compute(L, R)
+    assert m.search_variant == "fast_qsad", (D, w, m.search_variant)
+    m.close()
+    assert np.array_equal(got, oracle.bm_compute(L, R, **kw)), (D, w)
