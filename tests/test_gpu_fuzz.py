@@ -100,3 +100,21 @@ def test_every_fast_instantiation(pkg, oracle, synth, D, pieces):
     assert m.search_variant == "fast_qsad", (D, w, m.search_variant)
     m.close()
     assert np.array_equal(got, oracle.bm_compute(L, R, **kw)), (D, w)
+
+
+@pytest.mark.parametrize("W,H,D,w", [(4096, 48, 64, 9), (4095, 31, 128, 11), (90, 700, 64, 9), (70, 10, 64, 9), (25, 25, 16, 5),
+                                     (300, 6, 16, 5), (2050, 70, 256, 15), (1920, 1080, 64, 9)])
+def test_extreme_shapes(pkg, oracle, synth, W, H, D, w):
+    # widest supported row (4096: whole rows live in LDS), tall-and-narrow, barely larger than the window,
+    # fewer columns than disparities (all FILTERED), 1080p
+    L, R = synth.make_pair(synth.STREAM_SEED + 12000 + W + H, W, H, D)
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H)
+    got = m.compute(L, R)
+    m.close()
+    assert np.array_equal(got, oracle.bm_compute(L, R, numDisparities=D, blockSize=w, nthreads=8)), (W, H, D, w)
+
+
+def test_too_wide_is_refused_not_crashed(pkg):
+    with pytest.raises(pkg.binding.RtdmError) as e:
+        pkg.HIPMatcher(numOfDisparities=64, blockSize=9, width=4097, height=32)
+    assert e.value.status == -6
