@@ -216,6 +216,114 @@ __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, 
     }
 }
 
+struct alignas(16) Short8 { int16_t v[8]; };
+
+// Vector form of k_lrcheck<SPK, uint16_t, uint32_t, 1> for 16-byte-aligned rows with W % 8 == 0: one thread owns
+// 8 consecutive columns, so the row, its costs, the write-back and the head map each move as ONE 128-bit access
+// per thread (the scalar kernel spends its time issuing 2-byte accesses), and the run scan works on one
+// aggregate per thread instead of one LDS element per column.  Same results as the scalar kernel.
+template <bool SPK>
+__global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16_t* cost, BMGeom g, int maxDiff16,
+                                                     int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                                                     int16_t* headmap, int spkDiff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = g.W, INV = g.filtered;
+    uint32_t* key = (uint32_t*)smem;                                  // W keys: cost << 16 | x
+    int16_t* snap = (int16_t*)(key + W);                              // W: the row before the check
+    int16_t* fin = snap + W;                                          // W: the row after it (SPK)
+    __shared__ int wsum[8];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int x0 = tid * 8;
+    const bool active = x0 < W;
+    const int f = blockIdx.z, y = g.vy0 + blockIdx.y;
+    const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
+    int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    const uint16_t* crow = cost + ((size_t)f * g.H + y) * W;
+    Short8 d8, c8;
+    if (active) {
+        d8 = *(const Short8*)(row + x0);
+        c8 = *(const Short8*)(crow + x0);
+        *(Short8*)(snap + x0) = d8;
+        const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
+        ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int x = x0 + k, d = d8.v[k];
+            if (d == INV || x < minX1 || x >= maxX1) continue;
+            const int x2 = x - ((d + 8) >> 4);
+            if (x2 < 0 || x2 >= W) continue;
+            atomicMin(&key[x2], ((uint32_t)(uint16_t)c8.v[k] << 16) | (uint32_t)x);
+        }
+    }
+    __syncthreads();
+    if (active) {
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int x = x0 + k, d = d8.v[k];
+            bool kill = (x < g.vx0 || x >= g.vx1);
+            if (!kill && d != INV && x >= minX1 && x < maxX1) {
+                const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
+                bool bad0 = false, bad1 = false;
+                if (xa >= 0 && xa < W) { const uint32_t q = key[xa]; if (q != ~0u) bad0 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
+                if (xb >= 0 && xb < W) { const uint32_t q = key[xb]; if (q != ~0u) bad1 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
+                kill = bad0 && bad1;
+            }
+            if (kill && d != INV) { d8.v[k] = (int16_t)INV; changed = true; }
+        }
+        if (changed) *(Short8*)(row + x0) = d8;
+        if (SPK) *(Short8*)(fin + x0) = d8;
+    }
+    if (!SPK) return;
+    __syncthreads();
+    // ---- speckle init of the finished row (what spk_row_init does, on per-thread aggregates) ----
+    int left = INV, right = INV;
+    if (active) { if (x0 > 0) left = fin[x0 - 1]; if (x0 + 8 < W) right = fin[x0 + 8]; }
+    unsigned hm = 0;
+    if (active) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int v = d8.v[k], pv = k ? (int)d8.v[k - 1] : left;
+            hm |= (unsigned)(v != INV && !conn(v, pv, INV, spkDiff)) << k;
+        }
+    }
+    const int agg = hm ? ((__builtin_popcount(hm) << 16) | (x0 + (31 - __builtin_clz(hm)) + 1)) : 0;
+    int t = agg;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(t, o);
+        if (lane >= o) t = OpHead::f(t, u);
+    }
+    if (lane == 63) wsum[wv] = t;
+    __syncthreads();
+    int run = __shfl_up(t, 1);
+    if (lane == 0) run = 0;
+    for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[q]);
+    if (!active) return;
+    const int base = (f * g.H + y) * W;
+    Short8 h8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = x0 + k, v = d8.v[k];
+        if ((hm >> k) & 1) run = (int)(((unsigned)run & 0xffff0000u) + 0x10000u) | (x + 1);
+        const int h = (run & 0xffff) - 1;
+        h8.v[k] = (int16_t)h;
+        if (v == INV) continue;
+        const int nv = k < 7 ? (int)d8.v[k + 1] : right;
+        if (conn(v, nv, INV, spkDiff)) continue;                 // not the last pixel of its run
+        const int len = x - h + 1;
+        label[base + h] = base + h;
+        size[base + h] = len;
+        runs[base + (run >> 16) - 1] = (uint32_t)h | ((uint32_t)len << 16);
+    }
+    *(Short8*)(headmap + base + x0) = h8;
+    if (x0 + 8 >= W) rowcnt[f * g.H + y] = run >> 16;
+}
+
 void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
                     hipStream_t stream, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                     int16_t* headmap, int spkDiff)
@@ -229,7 +337,14 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
     hipLaunchKernelGGL((k_lrcheck<SPK, CT, KT, RR>), dim3(1, (nrows + RR - 1) / RR, n), block,                        \
                        (size_t)g.W * (kb + 2 + (SPK ? 4 * RR : 2 * RR)), stream, disp, (const CT*)cost, g, md, label, size, runs, \
                        rowcnt, headmap, spkDiff)
-    if (label) {
+    const bool vec = k32 && (g.W & 7) == 0 && g.W <= 4096 && lr_rows() == 1 &&
+                     (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2) | (size_t)cost | (size_t)headmap) & 15) == 0;
+    if (vec) {
+        const dim3 vblock((unsigned)(((g.W >> 3) + 63) & ~63));
+        const size_t lds = (size_t)g.W * 8;
+        if (label) hipLaunchKernelGGL(k_lrcheck_vec<true>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL(k_lrcheck_vec<false>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+    } else if (label) {
         const int rr = lr_rows();
         if (k32) { if (rr == 4) RTDM_LR(true, uint16_t, uint32_t, 4); else if (rr == 2) RTDM_LR(true, uint16_t, uint32_t, 2); else RTDM_LR(true, uint16_t, uint32_t, 1); }
         else if (g.cost16) { if (rr == 4) RTDM_LR(true, uint16_t, unsigned long long, 4); else if (rr == 2) RTDM_LR(true, uint16_t, unsigned long long, 2); else RTDM_LR(true, uint16_t, unsigned long long, 1); }
@@ -278,17 +393,19 @@ __global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label,
 // merge: one thread = 8 consecutive pixels of a row pair (y, y+1); no LDS, no scans: the heads come
 // from the head map.  A pixel is skipped when its left neighbour already linked the same two runs.
 // VEC: rows are 16-byte aligned, so the 8 pixels of each row come in as one 128-bit load.
-struct alignas(16) Short8 { int16_t v[8]; };
 
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int H,
                                                    int y_lo, int npairs, int ystep, int newVal, int maxDiff)
 {
-    // pairs (y, y+1) for y = y_lo + k * ystep, k < npairs
+    // pairs (y, y+1) for y = y_lo + k * ystep, k < npairs.  The kernel is bound by the number of load instructions
+    // (a 2-byte-per-lane load costs the address unit as much as a 16-byte one), so the left-neighbour state comes
+    // from lane-1's registers; only lane 0 of a wave fetches it from memory.
     const int nxb = (W + 7) / 8;
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nxb * npairs) return;
-    const int y = y_lo + (idx / nxb) * ystep, x0 = (idx % nxb) * 8;
+    const bool inb = idx < nxb * npairs;
+    const int cidx = inb ? idx : 0;
+    const int y = y_lo + (cidx / nxb) * ystep, x0 = (cidx % nxb) * 8;
     const int f = blockIdx.y;
     const int16_t* d0 = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     const int16_t* d1 = d0 + disp.pitch_e;
@@ -297,29 +414,41 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
     const int16_t* h1 = headmap + base1;
     Short8 a8, b8, ha8, hb8;
     const bool full = VEC && x0 + 8 <= W;
-    if (full) {
-        a8 = *(const Short8*)(d0 + x0); b8 = *(const Short8*)(d1 + x0);
-    } else {
-        for (int k = 0; k < 8; ++k) { const int x = min(x0 + k, W - 1); a8.v[k] = d0[x]; b8.v[k] = d1[x]; }
-    }
-    bool any = false;
+    unsigned cm = 0;
+    if (inb) {
+        if (full) {
+            a8 = *(const Short8*)(d0 + x0); b8 = *(const Short8*)(d1 + x0);
+        } else {
+            for (int k = 0; k < 8; ++k) { const int x = min(x0 + k, W - 1); a8.v[k] = d0[x]; b8.v[k] = d1[x]; }
+        }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) any |= conn(a8.v[k], b8.v[k], newVal, maxDiff);
-    if (!any) return;
-    if (full) {
-        ha8 = *(const Short8*)(h0 + x0); hb8 = *(const Short8*)(h1 + x0);
-    } else {
-        for (int k = 0; k < 8; ++k) { const int x = min(x0 + k, W - 1); ha8.v[k] = h0[x]; hb8.v[k] = h1[x]; }
+        for (int k = 0; k < 8; ++k) cm |= (unsigned)((x0 + k < W) && conn(a8.v[k], b8.v[k], newVal, maxDiff)) << k;
     }
+    ha8.v[7] = hb8.v[7] = 0;
+    if (cm) {
+        if (full) {
+            ha8 = *(const Short8*)(h0 + x0); hb8 = *(const Short8*)(h1 + x0);
+        } else {
+            for (int k = 0; k < 8; ++k) { const int x = min(x0 + k, W - 1); ha8.v[k] = h0[x]; hb8.v[k] = h1[x]; }
+        }
+    }
+    // state of the pixel left of x0: lane-1 holds it in element 7 (same row whenever x0 > 0)
+    const int packed = (int)(cm >> 7) | ((int)(uint16_t)ha8.v[7] << 1) | ((int)(uint16_t)hb8.v[7] << 17);
+    const int fromLeft = __shfl_up(packed, 1);
+    if (!cm) return;
     bool pc = false;
-    int ph0 = -1, ph1 = -1;                                   // left neighbour state
+    int ph0 = -1, ph1 = -1;
     if (x0 > 0) {
-        pc = conn(d0[x0 - 1], d1[x0 - 1], newVal, maxDiff);
-        if (pc) { ph0 = h0[x0 - 1]; ph1 = h1[x0 - 1]; }
+        if ((threadIdx.x & 63) != 0) {
+            pc = fromLeft & 1; ph0 = (fromLeft >> 1) & 0xffff; ph1 = (fromLeft >> 17) & 0x7fff;
+        } else {
+            pc = conn(d0[x0 - 1], d1[x0 - 1], newVal, maxDiff);
+            if (pc) { ph0 = h0[x0 - 1]; ph1 = h1[x0 - 1]; }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const bool c = (x0 + k < W) && conn(a8.v[k], b8.v[k], newVal, maxDiff);
+        const bool c = (cm >> k) & 1;
         const int ha = ha8.v[k], hb = hb8.v[k];
         if (c && !(pc && ph0 == ha && ph1 == hb)) uf_union(label, base0 + ha, base1 + hb);
         pc = c; ph0 = ha; ph1 = hb;
