@@ -455,6 +455,67 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
     }
 }
 
+// Strip form of the merge for aligned rows: one thread walks RS consecutive row pairs of its 8 columns, so every
+// row of disparities / heads is loaded once instead of twice (as the lower row of one pair and the upper row of the
+// next).  Same unions as k_spk_merge<true> with ystep = 1.
+template <int RS>
+__global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int H,
+                                                         int y_lo, int npairs, int newVal, int maxDiff)
+{
+    const int nxb = W >> 3;
+    const int nstrips = (npairs + RS - 1) / RS;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const bool inb = idx < nxb * nstrips;
+    const int cidx = inb ? idx : 0;
+    const int strip = cidx / nxb, x0 = (cidx % nxb) * 8;
+    const int y = y_lo + strip * RS;
+    const int nr = inb ? min(RS, npairs - strip * RS) : 0;
+    const int f = blockIdx.y;
+    const int16_t* d = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e + x0;
+    int base = (f * H + y) * W;
+    const int16_t* h = headmap + base + x0;
+    Short8 a8, b8, ha8, hb8;
+    if (inb) a8 = *(const Short8*)d;
+    bool ha_loaded = false;
+#pragma unroll
+    for (int r = 0; r < RS; ++r) {
+        unsigned cm = 0;
+        if (r < nr) {
+            b8 = *(const Short8*)(d + disp.pitch_e);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) cm |= (unsigned)conn(a8.v[k], b8.v[k], newVal, maxDiff) << k;
+        }
+        hb8.v[7] = 0;
+        if (cm) {
+            if (!ha_loaded) ha8 = *(const Short8*)h;
+            hb8 = *(const Short8*)(h + W);
+        } else ha8.v[7] = 0;
+        const int packed = (int)(cm >> 7) | ((int)(uint16_t)ha8.v[7] << 1) | ((int)(uint16_t)hb8.v[7] << 17);
+        const int fromLeft = __shfl_up(packed, 1);
+        if (cm) {
+            bool pc = false;
+            int ph0 = -1, ph1 = -1;
+            if (x0 > 0) {
+                if ((threadIdx.x & 63) != 0) {
+                    pc = fromLeft & 1; ph0 = (fromLeft >> 1) & 0xffff; ph1 = (fromLeft >> 17) & 0x7fff;
+                } else {
+                    pc = conn(d[-1], d[disp.pitch_e - 1], newVal, maxDiff);
+                    if (pc) { ph0 = h[-1]; ph1 = h[W - 1]; }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const bool c = (cm >> k) & 1;
+                const int ha = ha8.v[k], hb = hb8.v[k];
+                if (c && !(pc && ph0 == ha && ph1 == hb)) uf_union(label, base + ha, base + W + hb);
+                pc = c; ph0 = ha; ph1 = hb;
+            }
+        }
+        a8 = b8; ha8 = hb8; ha_loaded = cm != 0;
+        d += disp.pitch_e; h += W; base += W;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, const uint32_t* runs,
                                                    const int32_t* rowcnt, int W, int nrows, int maxSize)
 {
@@ -514,6 +575,14 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         const int nxb = (W + 7) / 8;
         const bool vec = (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2)) & 15) == 0 && (W & 7) == 0;
         dim3 grid((nxb * npairs + 255) / 256, n);
+        static int rs = -1;
+        if (rs < 0) { const char* e = getenv("RTDM_MERGE_STRIP"); rs = e ? atoi(e) : 4; }
+        if (vec && step == 1 && rs > 1) {
+            const int RSV = rs >= 8 ? 8 : 4;
+            dim3 sgrid((nxb * ((npairs + RSV - 1) / RSV) + 255) / 256, n);
+            if (RSV == 8) hipLaunchKernelGGL(k_spk_merge_strip<8>, sgrid, block, 0, stream, disp, label, headmap, W, H, first, npairs, newVal, maxDiff);
+            else          hipLaunchKernelGGL(k_spk_merge_strip<4>, sgrid, block, 0, stream, disp, label, headmap, W, H, first, npairs, newVal, maxDiff);
+        } else
         if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, H, first, npairs, step, newVal, maxDiff);
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, H, first, npairs, step, newVal, maxDiff);
     }
