@@ -66,6 +66,72 @@ __global__ __launch_bounds__(256) void k_prefilter8(Plane8 L, Plane8 R, Plane8W 
     *(unsigned long long*)dst = out;                        // plane pitch is a multiple of 64: in bounds
 }
 
+// Strip variant for 16-byte aligned sources: one thread = 16 columns x RY rows.  Rows stream through registers (each
+// source row is loaded once per strip as ONE 128-bit load; k_prefilter8 issues nine 64-bit loads per 8 output
+// bytes and is bound by the load-issue rate), the bytes left and right of the 16 come from the neighbouring lanes.
+template <int RY>
+__global__ __launch_bounds__(256) void k_prefilter16(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp,
+                                                     int W, int H, int cap, int n, int nxb)
+{
+    const int nstrip = (H + RY - 1) / RY;
+    const int idx = blockIdx.x * 256 + threadIdx.x;        // over (strip, 16-byte block)
+    const bool inb = idx < nxb * nstrip;
+    const int cidx = inb ? idx : 0;
+    const int strip = cidx / nxb, x0 = (cidx - strip * nxb) * 16, ys = strip * RY;
+    const int lane = threadIdx.x & 63;
+    int f = blockIdx.y;
+    const bool right = f >= n;
+    if (right) f -= n;
+    const Plane8 S = right ? R : L;
+    const Plane8W O = right ? Rp : Lp;
+    const uint8_t* src = S.base + (size_t)f * S.frame + x0;
+    uint8_t* dst = O.base + (size_t)f * O.frame + (size_t)ys * O.pitch + x0;
+    const int npair = (H >= 2) ? (H & ~1) : 0;
+    const bool has_prev = x0 > 0, has_next = x0 + 16 < W;
+    const uint4 capv = make_uint4(cap * 0x01010101u, cap * 0x01010101u, cap * 0x01010101u, cap * 0x01010101u);
+    int hd[3][16];                                          // x-differences r[x+1] - r[x-1] of the last three rows
+#pragma unroll
+    for (int j = 0; j < RY + 2; ++j) {
+        int yy = ys + j - 1;                                // source row of this step (mirrored at the frame edge)
+        yy = yy < 0 ? 1 : (yy > H - 1 ? H - 2 : yy);
+        if (H < 2) yy = 0;
+        uint4 q = make_uint4(0, 0, 0, 0);
+        const uint8_t* rp = src + (size_t)yy * S.pitch;
+        if (inb) q = *(const uint4*)rp;
+        int lb = __shfl_up((int)(q.w >> 24), 1), rb = __shfl_down((int)(q.x & 0xff), 1);
+        if (inb && lane == 0 && has_prev) lb = rp[-1];
+        if (inb && lane == 63 && has_next) rb = rp[16];
+        int b[18];
+        b[0] = lb; b[17] = rb;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b[1 + k] = (q.x >> (8 * k)) & 0xff; b[5 + k] = (q.y >> (8 * k)) & 0xff;
+            b[9 + k] = (q.z >> (8 * k)) & 0xff; b[13 + k] = (q.w >> (8 * k)) & 0xff;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) hd[j % 3][k] = b[k + 2] - b[k];
+        if (j >= 2) {
+            const int y = ys + j - 2;                       // output row: rows (j-2, j-1, j) are (above, centre, below)
+            if (inb && y < H) {
+                uint4 o = capv;
+                if (y < npair) {
+                    unsigned w[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        const int x = x0 + k;
+                        int g = hd[(j - 2) % 3][k] + 2 * hd[(j - 1) % 3][k] + hd[j % 3][k];
+                        g = g < -cap ? -cap : (g > cap ? cap : g);
+                        const int v = (x == 0 || x >= W - 1) ? cap : g + cap;
+                        w[k >> 2] |= (unsigned)v << (8 * (k & 3));
+                    }
+                    o = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                *(uint4*)(dst + (size_t)(j - 2) * O.pitch) = o;   // plane pitch is a multiple of 64: in bounds
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_prefilter1(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp,
                                                     int W, int H, int cap, int n)
 {
@@ -96,6 +162,16 @@ __global__ __launch_bounds__(256) void k_prefilter1(Plane8 L, Plane8 R, Plane8W 
 void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, int cap, int n,
                       hipStream_t stream)
 {
+    const auto al16 = [](const Plane8& p) { return (((size_t)p.base | p.pitch | p.frame) & 15) == 0; };
+    const size_t w16 = (size_t)((W + 15) & ~15);
+    static int strip16 = -1;
+    if (strip16 < 0) { const char* e = getenv("RTDM_PREFILTER_STRIP"); strip16 = e ? atoi(e) : 1; }
+    if (strip16 && al16(L) && al16(R) && L.pitch >= w16 && R.pitch >= w16 && ((size_t)Lp.base & 15) == 0 && ((size_t)Rp.base & 15) == 0) {
+        constexpr int RY = 8;
+        const int nxb = (W + 15) / 16;
+        hipLaunchKernelGGL(k_prefilter16<RY>, dim3((nxb * ((H + RY - 1) / RY) + 255) / 256, 2 * n), dim3(256), 0, stream, L, R, Lp, Rp, W, H, cap, n, nxb);
+        return;
+    }
     const auto al8 = [](const Plane8& p) { return (((size_t)p.base | p.pitch | p.frame) & 7) == 0; };
     if (al8(L) && al8(R) && L.pitch >= (size_t)((W + 7) & ~7) && R.pitch >= (size_t)((W + 7) & ~7)) {
         const int nxb = (W + 7) / 8;
