@@ -173,6 +173,35 @@ int rtdm_depth_stats_device(int device, const int16_t* d_disp, size_t disp_pitch
                             const uint8_t* d_mask, size_t mask_pitch, const rtdm_region* regions, int nregions,
                             double calibration_unit, double* mean_cm, int* counts, void* hip_stream);
 
+/* ---- the step in front of the matcher, on the device --------------
+ * rtdm_rectify_create  <- the maps the reference builds once (main.cpp:95-96, initUndistortRectifyMap(..., CV_16SC2,
+ *                         map1, map2)): map1 = H x W x 2 int16 (source x, y), map2 = H x W uint16 (fy*32 + fx);
+ *                         roi = the crop `roif` applied to every remapped frame (main.cpp:80-85, estimator.cpp:33,36).
+ *                         Only the roi part of the maps is kept on the device.
+ * rtdm_rectify_gray    <- estimator.cpp:29-36: cvtColor(img[i], gray, CV_RGB2GRAY); remap(gray, rect, map1, map2,
+ *                         INTER_LINEAR); rect = rect(roif) for both cameras.  rgb: H x W x 3 bytes, first channel R;
+ *                         outputs: roi_h x roi_w bytes.
+ * rtdm_rectify_rgb     <- estimator.cpp:38-39: remap(img[0], img_rectified, ...)(roif); out: roi_h x roi_w x 3.
+ * rtdm_bm_compute_rgb  <- estimator.cpp:29-36 + 56 in one call: the rectified gray pair never leaves HBM; the
+ *                         matcher must have been created for at least roi_w x roi_h.
+ * The *_device forms take n contiguous device frames (n x H x W x 3 in, n x roi_h x roi_w out). */
+typedef struct rtdm_rectify rtdm_rectify;
+int rtdm_rectify_create(const int16_t* map1_left, const uint16_t* map2_left, const int16_t* map1_right,
+                        const uint16_t* map2_right, int width, int height, int roi_x, int roi_y, int roi_width,
+                        int roi_height, int max_batch, int device, rtdm_rectify** out);
+void rtdm_rectify_destroy(rtdm_rectify* rc);
+int rtdm_rectify_gray(rtdm_rectify* rc, const uint8_t* rgb_left, size_t left_pitch, const uint8_t* rgb_right,
+                      size_t right_pitch, uint8_t* left_rect, size_t left_rect_pitch, uint8_t* right_rect,
+                      size_t right_rect_pitch);
+int rtdm_rectify_rgb(rtdm_rectify* rc, int which /* 0 = left maps, 1 = right maps */, const uint8_t* rgb, size_t pitch,
+                     uint8_t* out, size_t out_pitch);
+int rtdm_rectify_gray_device(rtdm_rectify* rc, int n, const uint8_t* d_rgb_left, const uint8_t* d_rgb_right,
+                             uint8_t* d_left_rect, uint8_t* d_right_rect, void* hip_stream);
+int rtdm_bm_compute_rgb(rtdm_bm* bm, rtdm_rectify* rc, const uint8_t* rgb_left, size_t left_pitch,
+                        const uint8_t* rgb_right, size_t right_pitch, int16_t* disp, size_t disp_pitch);
+int rtdm_bm_compute_rgb_device(rtdm_bm* bm, rtdm_rectify* rc, int n, const uint8_t* d_rgb_left,
+                               const uint8_t* d_rgb_right, int16_t* d_disp, void* hip_stream);
+
 /* ---- synthetic rectified-pair stream (stands in for stream/ + decoder/, which are out of
  * scope): frame f of the stream uses seed + f; bit-identical to rt-depth-map_amd/synth.py. */
 int rtdm_synth_pairs_device(uint64_t seed, int first_frame, int n, int width, int height,

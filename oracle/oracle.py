@@ -81,6 +81,16 @@ def lib():
         L.orc_depth_stats.argtypes = [i16p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, C.c_size_t,
                                       C.POINTER(C.c_int), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_depth_stats.restype = C.c_int
+        dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int)
+        L.orc_rgb2gray.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.orc_rgb2gray.restype = None
+        L.orc_remap_bilinear.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, i16p, u16p, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.orc_remap_bilinear.restype = None
+        for n in ("orc_rectify_gray", "orc_rectify_rgb"):
+            getattr(L, n).argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, i16p, u16p, ip, u8p, C.c_size_t]
+            getattr(L, n).restype = C.c_int
+        L.orc_init_undistort_rectify_map.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, i16p, u16p]
+        L.orc_init_undistort_rectify_map.restype = C.c_int
         _lib = L
     return _lib
 
@@ -225,3 +235,61 @@ def depth_stats(disp16, Q, mask, regions, calibration_unit=25.0):
     if rc != 0:
         raise ValueError("orc_depth_stats failed: %d" % rc)
     return mean, cnt
+
+
+# ---- rectification in front of the matcher (rectify_oracle.c) -------------------------------------------------
+def rgb2gray(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8); H, W, _ = rgb.shape
+    out = np.empty((H, W), np.uint8)
+    lib().orc_rgb2gray(_p(rgb, C.c_uint8), W * 3, W, H, _p(out, C.c_uint8), W)
+    return out
+
+
+def remap_bilinear(src, map1, map2):
+    """src: HxW or HxWx3 uint8; map1: dHxdWx2 int16; map2: dHxdW uint16 -> dHxdW(x3) uint8."""
+    src = np.ascontiguousarray(src, np.uint8)
+    cn = 1 if src.ndim == 2 else src.shape[2]
+    sH, sW = src.shape[:2]
+    map1 = np.ascontiguousarray(map1, np.int16); map2 = np.ascontiguousarray(map2, np.uint16)
+    dH, dW = map2.shape
+    out = np.empty((dH, dW) if cn == 1 else (dH, dW, cn), np.uint8)
+    lib().orc_remap_bilinear(_p(src, C.c_uint8), sW * cn, sW, sH, cn, _p(map1, C.c_int16), _p(map2, C.c_uint16), dW, dH,
+                             _p(out, C.c_uint8), dW * cn)
+    return out
+
+
+def rectify_gray(rgb, map1, map2, roi):
+    rgb = np.ascontiguousarray(rgb, np.uint8); H, W, _ = rgb.shape
+    map1 = np.ascontiguousarray(map1, np.int16); map2 = np.ascontiguousarray(map2, np.uint16)
+    r = (C.c_int * 4)(*roi)
+    out = np.empty((roi[3], roi[2]), np.uint8)
+    rc = lib().orc_rectify_gray(_p(rgb, C.c_uint8), W * 3, W, H, _p(map1, C.c_int16), _p(map2, C.c_uint16), r,
+                                _p(out, C.c_uint8), roi[2])
+    if rc != 0:
+        raise ValueError("orc_rectify_gray failed: %d" % rc)
+    return out
+
+
+def rectify_rgb(rgb, map1, map2, roi):
+    rgb = np.ascontiguousarray(rgb, np.uint8); H, W, _ = rgb.shape
+    map1 = np.ascontiguousarray(map1, np.int16); map2 = np.ascontiguousarray(map2, np.uint16)
+    r = (C.c_int * 4)(*roi)
+    out = np.empty((roi[3], roi[2], 3), np.uint8)
+    rc = lib().orc_rectify_rgb(_p(rgb, C.c_uint8), W * 3, W, H, _p(map1, C.c_int16), _p(map2, C.c_uint16), r,
+                               _p(out, C.c_uint8), roi[2] * 3)
+    if rc != 0:
+        raise ValueError("orc_rectify_rgb failed: %d" % rc)
+    return out
+
+
+def init_undistort_rectify_map(M, D, R, P, W, H):
+    """M 3x3, D up to 14 coefficients, R 3x3, P 3x4 -> (map1 HxWx2 int16, map2 HxW uint16)."""
+    m = np.ascontiguousarray(M, np.float64).reshape(9); r = np.ascontiguousarray(R, np.float64).reshape(9)
+    d = np.zeros(14, np.float64); dd = np.asarray(D, np.float64).reshape(-1); d[:len(dd)] = dd
+    p = np.ascontiguousarray(P, np.float64).reshape(12)
+    map1 = np.empty((H, W, 2), np.int16); map2 = np.empty((H, W), np.uint16)
+    dp = C.c_double
+    rc = lib().orc_init_undistort_rectify_map(_p(m, dp), _p(d, dp), _p(r, dp), _p(p, dp), W, H, _p(map1, C.c_int16), _p(map2, C.c_uint16))
+    if rc != 0:
+        raise ValueError("orc_init_undistort_rectify_map failed: %d" % rc)
+    return map1, map2

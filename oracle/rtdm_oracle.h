@@ -120,6 +120,19 @@ int orc_depth_stats(const int16_t* disp16, size_t dstep_elems, int W, int H, con
                     const uint8_t* mask, size_t mstep, const int* regions, int n,
                     double calibration_unit, double* mean_cm, int* counts);
 
+/* ---- rectification in front of the matcher (defined in rectify_oracle.c) ----------
+ * rgb: H x W x 3 bytes, first channel = R.  map1: H x W x 2 int16 (sx, sy), map2: H x W uint16 (fy*32 + fx).
+ * roi: x, y, width, height of the crop taken from the remapped frame (the reference's roif, main.cpp:80-85). */
+void orc_rgb2gray(const uint8_t* rgb, size_t sstep, int W, int H, uint8_t* gray, size_t dstep);
+void orc_remap_bilinear(const uint8_t* src, size_t sstep, int sW, int sH, int cn, const int16_t* map1,
+                        const uint16_t* map2, int dW, int dH, uint8_t* dst, size_t dstep);
+int orc_rectify_gray(const uint8_t* rgb, size_t sstep, int W, int H, const int16_t* map1, const uint16_t* map2,
+                     const int roi[4], uint8_t* out, size_t ostep);
+int orc_rectify_rgb(const uint8_t* rgb, size_t sstep, int W, int H, const int16_t* map1, const uint16_t* map2,
+                    const int roi[4], uint8_t* out, size_t ostep);
+int orc_init_undistort_rectify_map(const double M[9], const double D[14], const double R[9], const double P[12],
+                                   int W, int H, int16_t* map1, uint16_t* map2);
+
 #ifdef __cplusplus
 }
 #endif

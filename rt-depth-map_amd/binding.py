@@ -48,7 +48,7 @@ def lib():
         raise RuntimeError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
-    vp, u8p, i16p, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t
+    vp, u8p, i16p, u16p, sz = C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t
     sig = {
         "rtdm_strerror": (C.c_char_p, [C.c_int]),
         "rtdm_last_hip_error": (C.c_char_p, []),
@@ -82,6 +82,14 @@ def lib():
                                             C.POINTER(Region), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), i16p, sz]),
         "rtdm_depth_stats_device": (C.c_int, [C.c_int, i16p, sz, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, sz,
                                               C.POINTER(Region), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), vp]),
+        "rtdm_rectify_create": (C.c_int, [i16p, u16p, i16p, u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_int, C.POINTER(vp)]),
+        "rtdm_rectify_destroy": (None, [vp]),
+        "rtdm_rectify_gray": (C.c_int, [vp, u8p, sz, u8p, sz, u8p, sz, u8p, sz]),
+        "rtdm_rectify_rgb": (C.c_int, [vp, C.c_int, u8p, sz, u8p, sz]),
+        "rtdm_rectify_gray_device": (C.c_int, [vp, C.c_int, u8p, u8p, u8p, u8p, vp]),
+        "rtdm_bm_compute_rgb": (C.c_int, [vp, vp, u8p, sz, u8p, sz, i16p, sz]),
+        "rtdm_bm_compute_rgb_device": (C.c_int, [vp, vp, C.c_int, u8p, u8p, i16p, vp]),
         "rtdm_synth_pairs_device": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p,
                                               sz, sz, C.c_int, vp]),
     }
@@ -98,7 +106,9 @@ EXPORTS = ("rtdm_strerror rtdm_last_hip_error rtdm_abi_version rtdm_device_count
            "rtdm_bm_get_stage_time rtdm_bm_reset_stage_times rtdm_bm_search_variant rtdm_morph_create "
            "rtdm_morph_destroy rtdm_morph_in_buffer rtdm_morph_out_buffer rtdm_morph_run "
            "rtdm_morph_run_device rtdm_synth_pairs_device rtdm_sgm_default_params rtdm_sgm_create rtdm_sgm_destroy "
-           "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_bm_compute_depth rtdm_depth_stats_device").split()
+           "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_bm_compute_depth rtdm_depth_stats_device "
+           "rtdm_rectify_create rtdm_rectify_destroy rtdm_rectify_gray rtdm_rectify_rgb rtdm_rectify_gray_device "
+           "rtdm_bm_compute_rgb rtdm_bm_compute_rgb_device").split()
 
 
 def check(status, where):

@@ -194,6 +194,19 @@ __global__ __launch_bounds__(256) void k_fill16(Plane16W d, int x0, int x1, int 
     for (int x = xs; x < min(xs + 16, x1); ++x) p[x] = (int16_t)value;
 }
 
+__global__ __launch_bounds__(256) void k_copy16(Plane16W src, Plane16W dst, int W, int H)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W * H) return;
+    const int y = idx / W, x = idx - y * W;
+    dst.base[(size_t)blockIdx.y * dst.frame_e + (size_t)y * dst.pitch_e + x] = src.base[(size_t)blockIdx.y * src.frame_e + (size_t)y * src.pitch_e + x];
+}
+
+void launch_copy16(Plane16W src, Plane16W dst, int W, int H, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_copy16, dim3((W * H + 255) / 256, n), dim3(256), 0, stream, src, dst, W, H);
+}
+
 void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int value, hipStream_t stream)
 {
     if (x1 <= x0 || y1 <= y0) return;
@@ -243,7 +256,7 @@ __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, 
     for (int r = 0; r < nr; ++r) {
         const int y = yb + r;
         int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-        const CT* crow = cost + ((size_t)f * g.H + y) * W;
+        const CT* crow = cost + ((size_t)f * g.H + y) * g.Ws;
         int16_t* fin = finb + (size_t)r * W;
         for (int x = threadIdx.x; x < W; x += nt) { key[x] = NONE; snap[x] = row[x]; }
         __syncthreads();
@@ -270,7 +283,7 @@ __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, 
         }
         __syncthreads();
         if (SPK) {
-            const int base = (f * g.H + y) * W;           // the keys are no longer needed: scan scratch
+            const int base = (f * g.H + y) * g.Ws;        // the keys are no longer needed: scan scratch
             // only the block's first and last row meet rows of other blocks: they alone need the global map
             spk_row_init(fin, sc, wsum, W, base, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff,
                          hmb + (size_t)r * W, r == 0 || r == R - 1 || r == nr - 1);
@@ -282,7 +295,7 @@ __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, 
         // agent-scope loads, so they are visible here
         for (int r = 0; r + 1 < nr; ++r) {
             const int16_t *d0 = finb + (size_t)r * W, *d1 = d0 + W, *h0 = hmb + (size_t)r * W, *h1 = h0 + W;
-            const int base0 = (f * g.H + yb + r) * W, base1 = base0 + W;
+            const int base0 = (f * g.H + yb + r) * g.Ws, base1 = base0 + g.Ws;
             for (int x = threadIdx.x; x < W; x += nt) {
                 if (!conn(d0[x], d1[x], INV, spkDiff)) continue;
                 const bool dup = x > 0 && conn(d0[x - 1], d1[x - 1], INV, spkDiff) && h0[x - 1] == h0[x] && h1[x - 1] == h1[x];
@@ -305,9 +318,10 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = g.W, INV = g.filtered;
-    uint32_t* key = (uint32_t*)smem;                                  // W keys: cost << 16 | x
-    int16_t* snap = (int16_t*)(key + W);                              // W: the row before the check
-    int16_t* fin = snap + W;                                          // W: the row after it (SPK)
+    const int Wp = (W + 7) & ~7;                                      // LDS rows hold whole 8-column chunks
+    uint32_t* key = (uint32_t*)smem;                                  // Wp keys: cost << 16 | x
+    int16_t* snap = (int16_t*)(key + Wp);                             // Wp: the row before the check
+    int16_t* fin = snap + Wp;                                         // Wp: the row after it (SPK)
     __shared__ int wsum[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0 = tid * 8;
@@ -315,11 +329,13 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     const int f = blockIdx.z, y = g.vy0 + blockIdx.y;
     const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
     int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const uint16_t* crow = cost + ((size_t)f * g.H + y) * W;
+    const uint16_t* crow = cost + ((size_t)f * g.H + y) * g.Ws;
     Short8 d8, c8;
     if (active) {
         d8 = *(const Short8*)(row + x0);
         c8 = *(const Short8*)(crow + x0);
+        if (x0 + 8 > W)                                   // ragged last chunk: the plane's padding columns do not exist
+            for (int k = 0; k < 8; ++k) if (x0 + k >= W) d8.v[k] = (int16_t)INV;
         *(Short8*)(snap + x0) = d8;
         const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
         ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     if (lane == 0) run = 0;
     for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[q]);
     if (!active) return;
-    const int base = (f * g.H + y) * W;
+    const int base = (f * g.H + y) * g.Ws;
     Short8 h8;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -413,11 +429,12 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
     hipLaunchKernelGGL((k_lrcheck<SPK, CT, KT, RR>), dim3(1, (nrows + RR - 1) / RR, n), block,                        \
                        (size_t)g.W * (kb + 2 + (SPK ? 4 * RR : 2 * RR)), stream, disp, (const CT*)cost, g, md, label, size, runs, \
                        rowcnt, headmap, spkDiff)
-    const bool vec = k32 && (g.W & 7) == 0 && g.W <= 4096 && lr_rows() == 1 &&
+    const int Wp = (g.W + 7) & ~7;                      // a ragged last chunk is masked in registers; it needs padding columns
+    const bool vec = k32 && (g.Ws & 7) == 0 && g.W <= 4096 && lr_rows() == 1 && disp.pitch_e >= (size_t)Wp &&   // that belong to the plane
                      (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2) | (size_t)cost | (size_t)headmap) & 15) == 0;
     if (vec) {
-        const dim3 vblock((unsigned)(((g.W >> 3) + 63) & ~63));
-        const size_t lds = (size_t)g.W * 8;
+        const dim3 vblock((unsigned)(((Wp >> 3) + 63) & ~63));
+        const size_t lds = (size_t)Wp * 8;
         if (label) hipLaunchKernelGGL(k_lrcheck_vec<true>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
         else       hipLaunchKernelGGL(k_lrcheck_vec<false>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
     } else if (label) {
@@ -453,7 +470,7 @@ int lrcheck_rows_per_block() { return lr_rows(); }
 // components is independent of scheduling.  Components never span frames.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs,
-                                                  int32_t* rowcnt, int16_t* headmap, int W, int H, int newVal, int maxDiff)
+                                                  int32_t* rowcnt, int16_t* headmap, int W, int Ws, int H, int newVal, int maxDiff)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* sc = (int*)smem;                 // W
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label,
     const int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     for (int x = threadIdx.x; x < W; x += 256) d[x] = row[x];
     __syncthreads();
-    spk_row_init(d, sc, wsum, W, (f * H + y) * W, label, size, runs, rowcnt + (f * H + y), headmap, newVal, maxDiff);
+    spk_row_init(d, sc, wsum, W, (f * H + y) * Ws, label, size, runs, rowcnt + (f * H + y), headmap, newVal, maxDiff);
 }
 
 // merge: one thread = 8 consecutive pixels of a row pair (y, y+1); no LDS, no scans: the heads come
@@ -471,7 +488,7 @@ __global__ __launch_bounds__(256) void k_spk_init(Plane16W disp, int32_t* label,
 // VEC: rows are 16-byte aligned, so the 8 pixels of each row come in as one 128-bit load.
 
 template <bool VEC>
-__global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int H,
+__global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int Ws, int H,
                                                    int y_lo, int npairs, int ystep, int newVal, int maxDiff)
 {
     // pairs (y, y+1) for y = y_lo + k * ystep, k < npairs.  The kernel is bound by the number of load instructions
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
     const int f = blockIdx.y;
     const int16_t* d0 = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     const int16_t* d1 = d0 + disp.pitch_e;
-    const int base0 = (f * H + y) * W, base1 = base0 + W;
+    const int base0 = (f * H + y) * Ws, base1 = base0 + Ws;
     const int16_t* h0 = headmap + base0;
     const int16_t* h1 = headmap + base1;
     Short8 a8, b8, ha8, hb8;
@@ -535,10 +552,10 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
 // row of disparities / heads is loaded once instead of twice (as the lower row of one pair and the upper row of the
 // next).  Same unions as k_spk_merge<true> with ystep = 1.
 template <int RS>
-__global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int H,
+__global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int Ws, int H,
                                                          int y_lo, int npairs, int newVal, int maxDiff)
 {
-    const int nxb = W >> 3;
+    const int nxb = (W + 7) >> 3;                         // a ragged last chunk reads the plane's padding columns and masks them
     const int nstrips = (npairs + RS - 1) / RS;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const bool inb = idx < nxb * nstrips;
@@ -548,8 +565,9 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     const int nr = inb ? min(RS, npairs - strip * RS) : 0;
     const int f = blockIdx.y;
     const int16_t* d = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e + x0;
-    int base = (f * H + y) * W;
+    int base = (f * H + y) * Ws;
     const int16_t* h = headmap + base + x0;
+    const unsigned colmask = x0 + 8 <= W ? 0xffu : (0xffu >> (x0 + 8 - W));
     Short8 a8, b8, ha8, hb8;
     if (inb) a8 = *(const Short8*)d;
     bool ha_loaded = false;
@@ -560,11 +578,12 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
             b8 = *(const Short8*)(d + disp.pitch_e);
 #pragma unroll
             for (int k = 0; k < 8; ++k) cm |= (unsigned)conn(a8.v[k], b8.v[k], newVal, maxDiff) << k;
+            cm &= colmask;
         }
         hb8.v[7] = 0;
         if (cm) {
             if (!ha_loaded) ha8 = *(const Short8*)h;
-            hb8 = *(const Short8*)(h + W);
+            hb8 = *(const Short8*)(h + Ws);
         } else ha8.v[7] = 0;
         const int packed = (int)(cm >> 7) | ((int)(uint16_t)ha8.v[7] << 1) | ((int)(uint16_t)hb8.v[7] << 17);
         const int fromLeft = __shfl_up(packed, 1);
@@ -576,28 +595,28 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
                     pc = fromLeft & 1; ph0 = (fromLeft >> 1) & 0xffff; ph1 = (fromLeft >> 17) & 0x7fff;
                 } else {
                     pc = conn(d[-1], d[disp.pitch_e - 1], newVal, maxDiff);
-                    if (pc) { ph0 = h[-1]; ph1 = h[W - 1]; }
+                    if (pc) { ph0 = h[-1]; ph1 = h[Ws - 1]; }
                 }
             }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const bool c = (cm >> k) & 1;
                 const int ha = ha8.v[k], hb = hb8.v[k];
-                if (c && !(pc && ph0 == ha && ph1 == hb)) uf_union(label, base + ha, base + W + hb);
+                if (c && !(pc && ph0 == ha && ph1 == hb)) uf_union(label, base + ha, base + Ws + hb);
                 pc = c; ph0 = ha; ph1 = hb;
             }
         }
         a8 = b8; ha8 = hb8; ha_loaded = cm != 0;
-        d += disp.pitch_e; h += W; base += W;
+        d += disp.pitch_e; h += Ws; base += Ws;
     }
 }
 
 __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, const uint32_t* runs,
-                                                   const int32_t* rowcnt, int W, int nrows, int maxSize)
+                                                   const int32_t* rowcnt, int Ws, int nrows, int maxSize)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);        // one wave per row of the batch
     if (row >= nrows) return;
-    const int cnt = rowcnt[row], base = row * W;
+    const int cnt = rowcnt[row], base = row * Ws;
     for (int i = threadIdx.x & 63; i < cnt; i += 64) {
         const uint32_t rn = runs[base + i];
         const int idx = base + (int)(rn & 0xffffu), len = (int)(rn >> 16);
@@ -609,12 +628,12 @@ __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size
 }
 
 __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t* label, const int32_t* size,
-                                                   const uint32_t* runs, const int32_t* rowcnt, int W, int H, int nrows,
+                                                   const uint32_t* runs, const int32_t* rowcnt, int Ws, int H, int nrows,
                                                    int newVal, int maxSize)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= nrows) return;
-    const int cnt = rowcnt[row], base = row * W;
+    const int cnt = rowcnt[row], base = row * Ws;
     const int f = row / H, y = row - f * H;
     int16_t* drow = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     for (int i = threadIdx.x & 63; i < cnt; i += 64) {
@@ -632,14 +651,14 @@ __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t*
 // label/size/runs/headmap: n*W*H elements each; rowcnt: n*H.  If init_done, the rows [y_lo, y_hi) were
 // initialised by k_lrcheck<true> (rowcnt was zeroed before it) and no other row holds a valid pixel.
 void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
-                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
+                    int W, int Ws, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
                     int y_lo, int y_hi, hipStream_t stream)
 {
     dim3 block(256);
     if (!init_done) {
         y_lo = 0; y_hi = H; premerged_rows = 1;
         hipLaunchKernelGGL(k_spk_init, dim3(1, H, n), block, (size_t)W * 6, stream, disp, label, size, runs, rowcnt, headmap,
-                           W, H, newVal, maxDiff);
+                           W, Ws, H, newVal, maxDiff);
     }
     // row pairs still to merge: (y, y+1), y = first + k*step.  The init pass may already have merged the pairs
     // inside blocks of premerged_rows rows (k_lrcheck<SPK>); then only the pairs across blocks remain.
@@ -649,22 +668,23 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
     const int npairs = last >= first ? (last - first) / step + 1 : 0;
     if (npairs > 0) {
         const int nxb = (W + 7) / 8;
-        const bool vec = (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2)) & 15) == 0 && (W & 7) == 0;
+        const bool vec = (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2)) & 15) == 0 && (Ws & 7) == 0 &&
+                         disp.pitch_e >= (size_t)((W + 7) & ~7);   // a ragged last chunk reads (never writes) padding columns
         dim3 grid((nxb * npairs + 255) / 256, n);
         static int rs = -1;
         if (rs < 0) { const char* e = getenv("RTDM_MERGE_STRIP"); rs = e ? atoi(e) : 4; }
         if (vec && step == 1 && rs > 1) {
             const int RSV = rs >= 8 ? 8 : 4;
             dim3 sgrid((nxb * ((npairs + RSV - 1) / RSV) + 255) / 256, n);
-            if (RSV == 8) hipLaunchKernelGGL(k_spk_merge_strip<8>, sgrid, block, 0, stream, disp, label, headmap, W, H, first, npairs, newVal, maxDiff);
-            else          hipLaunchKernelGGL(k_spk_merge_strip<4>, sgrid, block, 0, stream, disp, label, headmap, W, H, first, npairs, newVal, maxDiff);
+            if (RSV == 8) hipLaunchKernelGGL(k_spk_merge_strip<8>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff);
+            else          hipLaunchKernelGGL(k_spk_merge_strip<4>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff);
         } else
-        if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, H, first, npairs, step, newVal, maxDiff);
-        else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, H, first, npairs, step, newVal, maxDiff);
+        if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
+        else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
     }
     const int nrows = n * H;
-    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 3) / 4), block, 0, stream, label, size, runs, rowcnt, W, nrows, maxSize);
-    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 3) / 4), block, 0, stream, disp, label, size, runs, rowcnt, W, H, nrows, newVal, maxSize);
+    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 3) / 4), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
+    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 3) / 4), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
 }
 
 }  // namespace rtdm

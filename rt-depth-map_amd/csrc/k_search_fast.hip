@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
                 out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
             }
             if (active) {
-                if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = (uint16_t)m1;
+                if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)m1;
                 db[(size_t)y * disp.pitch_e + col] = (int16_t)(masked_col ? g.filtered : out);
             }
         }

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
                 const int den = pp + nn - 2 * m1 + abs(pp - nn);
                 const int v = (D - mi - 1 + g.minD) * 256 + (den != 0 ? (pp - nn) * 256 / den : 0) + 15;
                 out = v >> 4;
-                if (g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = (T)m1;
+                if (g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (T)m1;
             }
             if (g.mask_cols && (col < g.vx0 || col >= g.vx1)) out = g.filtered;
             db[(size_t)y * disp.pitch_e + col] = (int16_t)out;

@@ -296,7 +296,7 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     const size_t lds = (size_t)g.W * (8 + 2 + 2 + 2);
     if (speckle) {
         launch_select<true>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, disp, g, uniq, disp12MaxDiff, b, 16 * speckleRange);
-        launch_speckle(disp, b.label, b.size, b.runs, b.rowcnt, b.headmap, g.W, g.H, n, (g.minD - 1) * 16, speckleWindowSize,
+        launch_speckle(disp, b.label, b.size, b.runs, b.rowcnt, b.headmap, g.W, g.W, g.H, n, (g.minD - 1) * 16, speckleWindowSize,
                        16 * speckleRange, true, 1, 0, g.H, stream);
     } else {
         launch_select<false>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, disp, g, uniq, disp12MaxDiff, b, 0);

@@ -37,6 +37,7 @@ struct Lane {
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
     int16_t* dHead;
+    int16_t* dOut;                 // internal disparity plane of the lane (rows of Ws elements)
 };
 
 struct rtdm_bm {
@@ -148,7 +149,8 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     for (int i = 0; i < RTDM_NUM_STAGES; ++i) { bm->stage_ms[i] = 0; bm->stage_launches[i] = 0; bm->stage_frames[i] = 0; }
     bm->ppitch = ((size_t)max_width + 63) & ~(size_t)63;
     const size_t plane = bm->ppitch * max_height * (size_t)max_batch;
-    const size_t px = (size_t)max_width * max_height * max_batch;
+    // per-pixel workspace and the internal disparity plane use rows of Ws = max_width rounded up to 8 elements
+    const size_t px = (size_t)((max_width + 7) & ~7) * max_height * max_batch;
     hipError_t e = hipStreamCreateWithFlags(&bm->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dLp, plane);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dRp, plane);
@@ -162,7 +164,7 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dHead, px * sizeof(int16_t));
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dMask, (size_t)max_width * max_height);
     if (e == hipSuccess) e = hipMalloc(&bm->dDepth, depth_scratch_bytes(RTDM_MAX_REGIONS, max_height));
-    bm->hStageBytes = 2 * bm->ppitch * (size_t)max_height + (size_t)max_width * max_height * (sizeof(int16_t) + 1) + 1024;
+    bm->hStageBytes = 2 * bm->ppitch * (size_t)max_height + (size_t)((max_width + 7) & ~7) * max_height * (sizeof(int16_t) + 1) + 1024;
     if (e == hipSuccess) e = hipHostMalloc((void**)&bm->hStage, bm->hStageBytes, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dRowCnt, (size_t)max_batch * max_height * sizeof(int32_t));
     if (e != hipSuccess) {
@@ -178,12 +180,12 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
         for (int k = 0; k < bm->nlanes; ++k) {
             Lane& ln = bm->lane[k];
             const size_t fo = (size_t)k * bm->laneB;                       // first frame of the slice
-            const size_t po = fo * max_width * max_height;                 // in pixels
+            const size_t po = fo * ((max_width + 7) & ~7) * max_height;     // in workspace pixels
             HIPC(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
             HIPC(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
             ln.dLp = bm->dLp + fo * bm->ppitch * max_height; ln.dRp = bm->dRp + fo * bm->ppitch * max_height;
             ln.dCost = bm->dCost + po; ln.dLabel = bm->dLabel + po; ln.dSize = bm->dSize + po;
-            ln.dRuns = bm->dRuns + po; ln.dHead = bm->dHead + po; ln.dRowCnt = bm->dRowCnt + fo * max_height;
+            ln.dRuns = bm->dRuns + po; ln.dHead = bm->dHead + po; ln.dOut = bm->dOut + po; ln.dRowCnt = bm->dRowCnt + fo * max_height;
         }
     }
     *out = bm;
@@ -229,7 +231,7 @@ int rtdm_bm_get_params(const rtdm_bm* bm, rtdm_bm_params* out)
 static bool make_geom(const rtdm_bm* bm, int W, int H, BMGeom* g)
 {
     const rtdm_bm_params& p = bm->p;
-    g->W = W; g->H = H; g->D = p.numDisparities; g->minD = p.minDisparity;
+    g->W = W; g->H = H; g->Ws = (W + 7) & ~7; g->D = p.numDisparities; g->minD = p.minDisparity;
     g->w = p.blockSize; g->r = p.blockSize / 2;
     g->cap = p.preFilterCap; g->tex = p.textureThreshold; g->uniq = p.uniquenessRatio;
     g->lofs = std::max(g->D - 1 + g->minD, 0);
@@ -275,8 +277,28 @@ static void stage_end(rtdm_bm* bm, hipStream_t s, StageEvent* ev)
     bm->pending.push_back(*ev);
 }
 
-// One chunk (n <= maxB) of device-resident frames, enqueued on `s`.
-static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s)
+static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s);
+
+// One chunk (n <= maxB) of device-resident frames, enqueued on `s`.  The row kernels move 8 columns per 128-bit
+// access and let a ragged last chunk spill into the row padding, so they need 16-byte aligned rows of at least
+// W rounded up to 8 elements whose padding is ours to write.  A caller's plane qualifies only if W % 8 == 0 and it
+// is aligned; anything else (the reference's own crops are 233, 534 and 934 columns wide) runs on the lane's
+// internal plane and is copied out at the end.
+static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W out, hipStream_t s)
+{
+    const size_t Ws = (size_t)((W + 7) & ~7);
+    const bool internal = out.base == ln.dOut && out.pitch_e == Ws;
+    const bool direct = internal || ((W & 7) == 0 && (((size_t)out.base | (out.pitch_e * 2) | (out.frame_e * 2)) & 15) == 0);
+    if (direct) return run_chunk_on(bm, ln, n, L, R, W, H, out, s);
+    Plane16W tmp{ln.dOut, Ws, Ws * (size_t)H};
+    const int rc = run_chunk_on(bm, ln, n, L, R, W, H, tmp, s);
+    if (rc) return rc;
+    launch_copy16(tmp, out, W, H, n, s);
+    HIPC(hipGetLastError());
+    return RTDM_OK;
+}
+
+static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s)
 {
     const rtdm_bm_params& p = bm->p;
     BMGeom g;
@@ -328,7 +350,7 @@ static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int
     }
     if (speckle) {
         stage_begin(bm, RTDM_STAGE_SPECKLE, n, s, &ev);
-        launch_speckle(disp, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, W, H, n, g.filtered, p.speckleWindowSize,
+        launch_speckle(disp, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, W, g.Ws, H, n, g.filtered, p.speckleWindowSize,
                        p.speckleRange, lr, lr ? lrcheck_rows_per_block() : 1, g.vy0, g.vy1, s);
         stage_end(bm, s, &ev);
     }
@@ -399,7 +421,8 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
     HIPC(hipSetDevice(bm->device));
     hipStream_t s = bm->stream;
     const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
-    const size_t opitch = (size_t)width * 2, oframe = opitch * (size_t)height;
+    const size_t Ws = (size_t)((width + 7) & ~7);                      // the lane's internal plane (see run_chunk)
+    const size_t opitch = Ws * 2, oframe = opitch * (size_t)height;
     for (int i0 = 0; i0 < n; i0 += bm->laneB) {
         const int m = std::min(bm->laneB, n - i0);
         for (int i = 0; i < m; ++i) {
@@ -409,12 +432,12 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
                                   width, height, hipMemcpyHostToDevice, s));
         }
         Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
-        Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
+        Plane16W O{bm->dOut, Ws, Ws * (size_t)height};
         rc = run_chunk(bm, bm->lane[0], m, L, R, width, height, O, s);
         if (rc) return rc;
         for (int i = 0; i < m; ++i)
             HIPC(hipMemcpy2DAsync((uint8_t*)disp + (size_t)(i0 + i) * disp_frame_stride, disp_pitch,
-                                  (uint8_t*)bm->dOut + i * oframe, opitch, opitch, height, hipMemcpyDeviceToHost, s));
+                                  (uint8_t*)bm->dOut + i * oframe, opitch, (size_t)width * 2, height, hipMemcpyDeviceToHost, s));
         HIPC(hipStreamSynchronize(s));   // staging buffers are reused by the next chunk
     }
     return RTDM_OK;
@@ -443,13 +466,14 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
     HIPC(hipMemcpyAsync(bm->dInL, hL, dframe, hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(bm->dInR, hR, dframe, hipMemcpyHostToDevice, s));
     Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
-    Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
+    const size_t Ws = (size_t)((width + 7) & ~7);                      // the lane's internal plane (see run_chunk)
+    Plane16W O{bm->dOut, Ws, Ws * (size_t)height};
     rc = run_chunk(bm, bm->lane[0], 1, L, R, width, height, O, s);
     if (rc) return rc;
-    HIPC(hipMemcpyAsync(hD, bm->dOut, (size_t)width * height * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(hD, bm->dOut, Ws * height * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
     for (int y = 0; y < height; ++y)
-        memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * width, (size_t)width * sizeof(int16_t));
+        memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * Ws, (size_t)width * sizeof(int16_t));
     return RTDM_OK;
 }
 
@@ -645,7 +669,7 @@ int rtdm_bm_compute_depth(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, c
     uint8_t* hL = bm->hStage;
     uint8_t* hR = hL + dframe;
     int16_t* hD = (int16_t*)(bm->hStage + 2 * bm->ppitch * (size_t)bm->maxH);
-    uint8_t* hM = (uint8_t*)(hD + (size_t)bm->maxW * bm->maxH);
+    uint8_t* hM = (uint8_t*)(hD + (size_t)((bm->maxW + 7) & ~7) * bm->maxH);
     for (int y = 0; y < height; ++y) {
         memcpy(hL + (size_t)y * dpitch, left + (size_t)y * left_pitch, (size_t)width);
         memcpy(hR + (size_t)y * dpitch, right + (size_t)y * right_pitch, (size_t)width);
@@ -655,18 +679,19 @@ int rtdm_bm_compute_depth(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, c
     HIPC(hipMemcpyAsync(bm->dInR, hR, dframe, hipMemcpyHostToDevice, s));
     HIPC(hipMemcpyAsync(bm->dMask, hM, (size_t)width * height, hipMemcpyHostToDevice, s));
     Plane8 L{bm->dInL, dpitch, dframe}, R{bm->dInR, dpitch, dframe};
-    Plane16W O{bm->dOut, (size_t)width, (size_t)width * height};
+    const size_t Ws = (size_t)((width + 7) & ~7);                      // the lane's internal plane (see run_chunk)
+    Plane16W O{bm->dOut, Ws, Ws * (size_t)height};
     rc = run_chunk(bm, bm->lane[0], 1, L, R, width, height, O, s);
     if (rc) return rc;
     DepthQ q; std::copy(Q, Q + 16, q.q);
-    launch_depth_stats(bm->dOut, (size_t)width, width, height, q, bm->dMask, (size_t)width, flat, nregions, bm->maxH,
+    launch_depth_stats(bm->dOut, Ws, width, height, q, bm->dMask, (size_t)width, flat, nregions, bm->maxH,
                        calibration_unit, bm->dDepth, mean_cm, counts, s);
-    if (disp) HIPC(hipMemcpyAsync(hD, bm->dOut, (size_t)width * height * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    if (disp) HIPC(hipMemcpyAsync(hD, bm->dOut, Ws * height * sizeof(int16_t), hipMemcpyDeviceToHost, s));
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(s));
     if (disp)
         for (int y = 0; y < height; ++y)
-            memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * width, (size_t)width * sizeof(int16_t));
+            memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * Ws, (size_t)width * sizeof(int16_t));
     return RTDM_OK;
 }
 
@@ -782,6 +807,208 @@ int rtdm_sgm_compute(rtdm_sgm* sg, const uint8_t* left, size_t left_pitch, const
     if (rc) return rc;
     HIPC(hipMemcpy2DAsync(disp, disp_pitch, sg->dOut, (size_t)width * 2, (size_t)width * 2, height, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    return RTDM_OK;
+}
+
+// ---- rectification in front of the matcher (estimator.cpp:29-39) ----------------------------------------------
+struct rtdm_rectify {
+    int W, H, rx, ry, rw, rh, maxB, device;
+    int16_t* dMap1[2];            // roi part of the maps: rh x rw x 2
+    uint16_t* dMap2[2];           // rh x rw
+    uint8_t* dRgb[2];             // staging for host frames: H x W x 3 (+ padding)
+    uint8_t* dOut;                // staging for host outputs: rh x rw x 3
+    uint8_t* dGray[2];            // rectified gray pair for the chained matcher call: rh x pitch
+    size_t gpitch;
+    uint8_t* hStage;              // pinned: 2 RGB frames in, rh x rw x 3 out
+    hipStream_t stream;
+};
+
+void rtdm_rectify_destroy(rtdm_rectify* rc)
+{
+    if (!rc) return;
+    (void)hipSetDevice(rc->device);
+    if (rc->stream) (void)hipStreamSynchronize(rc->stream);
+    void* bufs[] = {rc->dMap1[0], rc->dMap1[1], rc->dMap2[0], rc->dMap2[1], rc->dRgb[0], rc->dRgb[1], rc->dOut, rc->dGray[0], rc->dGray[1]};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (rc->hStage) (void)hipHostFree(rc->hStage);
+    if (rc->stream) (void)hipStreamDestroy(rc->stream);
+    delete rc;
+}
+
+int rtdm_rectify_create(const int16_t* map1_left, const uint16_t* map2_left, const int16_t* map1_right,
+                        const uint16_t* map2_right, int width, int height, int roi_x, int roi_y, int roi_width,
+                        int roi_height, int max_batch, int device, rtdm_rectify** out)
+{
+    if (!map1_left || !map2_left || !map1_right || !map2_right || !out) return RTDM_ERR_NULL;
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 32767 || height > 32767 || max_batch <= 0) return RTDM_ERR_BAD_SIZE;
+    if (roi_x < 0 || roi_y < 0 || roi_width <= 0 || roi_height <= 0 || roi_x + roi_width > width || roi_y + roi_height > height)
+        return RTDM_ERR_BAD_SIZE;
+    int st = use_device(device);
+    if (st) return st;
+    rtdm_rectify* rc = new (std::nothrow) rtdm_rectify();
+    if (!rc) return RTDM_ERR_NOMEM;
+    rc->W = width; rc->H = height; rc->rx = roi_x; rc->ry = roi_y; rc->rw = roi_width; rc->rh = roi_height;
+    rc->maxB = max_batch; rc->device = device;
+    rc->gpitch = ((size_t)roi_width + 63) & ~(size_t)63;
+    const size_t npx = (size_t)roi_width * roi_height, fbytes = (size_t)width * height * 3;
+    hipError_t e = hipStreamCreateWithFlags(&rc->stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc((void**)&rc->dMap1[k], npx * 4);
+        if (e == hipSuccess) e = hipMalloc((void**)&rc->dMap2[k], npx * 2);
+        if (e == hipSuccess) e = hipMalloc((void**)&rc->dRgb[k], fbytes + 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&rc->dGray[k], rc->gpitch * roi_height * (size_t)max_batch);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&rc->dOut, npx * 3);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&rc->hStage, 2 * fbytes + npx * 3, hipHostMallocDefault);
+    if (e == hipSuccess) {
+        // crop the maps on the host (through the pinned area), one linear copy each
+        for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+            const int16_t* m1 = k ? map1_right : map1_left;
+            const uint16_t* m2 = k ? map2_right : map2_left;
+            int16_t* h1 = (int16_t*)rc->hStage;
+            uint16_t* h2 = (uint16_t*)(rc->hStage + npx * 4);
+            for (int y = 0; y < roi_height; ++y) {
+                memcpy(h1 + (size_t)y * roi_width * 2, m1 + ((size_t)(roi_y + y) * width + roi_x) * 2, (size_t)roi_width * 4);
+                memcpy(h2 + (size_t)y * roi_width, m2 + (size_t)(roi_y + y) * width + roi_x, (size_t)roi_width * 2);
+            }
+            e = hipMemcpy(rc->dMap1[k], h1, npx * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(rc->dMap2[k], h2, npx * 2, hipMemcpyHostToDevice);
+        }
+    }
+    if (e != hipSuccess) {
+        g_hip_err = std::string("rtdm_rectify_create: ") + hipGetErrorString(e);
+        rtdm_rectify_destroy(rc);
+        return e == hipErrorOutOfMemory ? RTDM_ERR_NOMEM : RTDM_ERR_HIP;
+    }
+    *out = rc;
+    return RTDM_OK;
+}
+
+// host RGB frames -> dRgb[0/1] through the pinned staging area
+static int rectify_upload(rtdm_rectify* rc, const uint8_t* a, size_t apitch, const uint8_t* b, size_t bpitch, hipStream_t s)
+{
+    const size_t row = (size_t)rc->W * 3, fbytes = row * rc->H;
+    const uint8_t* src[2] = {a, b};
+    const size_t pit[2] = {apitch, bpitch};
+    for (int k = 0; k < 2; ++k) {
+        if (!src[k]) continue;
+        uint8_t* h = rc->hStage + k * fbytes;
+        if (pit[k] == row) memcpy(h, src[k], fbytes);
+        else for (int y = 0; y < rc->H; ++y) memcpy(h + (size_t)y * row, src[k] + (size_t)y * pit[k], row);
+        HIPC(hipMemcpyAsync(rc->dRgb[k], h, fbytes, hipMemcpyHostToDevice, s));
+    }
+    return RTDM_OK;
+}
+
+static void rectify_gray_launch(rtdm_rectify* rc, const uint8_t* dl, const uint8_t* dr, int n, Plane8W ol, Plane8W orr, hipStream_t s)
+{
+    const size_t row = (size_t)rc->W * 3, fbytes = row * rc->H;
+    RectifySrc L{dl, row, fbytes}, R{dr, row, fbytes};
+    launch_rectify_gray(L, R, rc->dMap1[0], rc->dMap2[0], rc->dMap1[1], rc->dMap2[1], rc->W, rc->H, rc->rw, rc->rh, ol, orr, n, s);
+}
+
+int rtdm_rectify_gray(rtdm_rectify* rc, const uint8_t* rgb_left, size_t left_pitch, const uint8_t* rgb_right,
+                      size_t right_pitch, uint8_t* left_rect, size_t left_rect_pitch, uint8_t* right_rect,
+                      size_t right_rect_pitch)
+{
+    if (!rc || !rgb_left || !rgb_right || !left_rect || !right_rect) return RTDM_ERR_NULL;
+    const size_t row = (size_t)rc->W * 3;
+    if (left_pitch < row || right_pitch < row || left_rect_pitch < (size_t)rc->rw || right_rect_pitch < (size_t)rc->rw) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(rc->device));
+    hipStream_t s = rc->stream;
+    int st = rectify_upload(rc, rgb_left, left_pitch, rgb_right, right_pitch, s);
+    if (st) return st;
+    const size_t gframe = rc->gpitch * rc->rh;
+    rectify_gray_launch(rc, rc->dRgb[0], rc->dRgb[1], 1, Plane8W{rc->dGray[0], rc->gpitch, gframe}, Plane8W{rc->dGray[1], rc->gpitch, gframe}, s);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpy2DAsync(left_rect, left_rect_pitch, rc->dGray[0], rc->gpitch, rc->rw, rc->rh, hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpy2DAsync(right_rect, right_rect_pitch, rc->dGray[1], rc->gpitch, rc->rw, rc->rh, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    return RTDM_OK;
+}
+
+int rtdm_rectify_rgb(rtdm_rectify* rc, int which, const uint8_t* rgb, size_t pitch, uint8_t* out, size_t out_pitch)
+{
+    if (!rc || !rgb || !out) return RTDM_ERR_NULL;
+    const size_t row = (size_t)rc->W * 3, fbytes = row * rc->H;
+    if ((which != 0 && which != 1) || pitch < row || out_pitch < (size_t)rc->rw * 3) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(rc->device));
+    hipStream_t s = rc->stream;
+    int st = rectify_upload(rc, rgb, pitch, nullptr, 0, s);
+    if (st) return st;
+    launch_rectify_rgb(RectifySrc{rc->dRgb[0], row, fbytes}, rc->dMap1[which], rc->dMap2[which], rc->W, rc->H, rc->rw, rc->rh,
+                       Plane8W{rc->dOut, (size_t)rc->rw * 3, (size_t)rc->rw * 3 * rc->rh}, 1, s);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpy2DAsync(out, out_pitch, rc->dOut, (size_t)rc->rw * 3, (size_t)rc->rw * 3, rc->rh, hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    return RTDM_OK;
+}
+
+int rtdm_rectify_gray_device(rtdm_rectify* rc, int n, const uint8_t* d_rgb_left, const uint8_t* d_rgb_right,
+                             uint8_t* d_left_rect, uint8_t* d_right_rect, void* hip_stream)
+{
+    if (!rc || !d_rgb_left || !d_rgb_right || !d_left_rect || !d_right_rect) return RTDM_ERR_NULL;
+    if (n <= 0) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(rc->device));
+    const size_t oframe = (size_t)rc->rw * rc->rh;
+    rectify_gray_launch(rc, d_rgb_left, d_rgb_right, n, Plane8W{d_left_rect, (size_t)rc->rw, oframe},
+                        Plane8W{d_right_rect, (size_t)rc->rw, oframe}, (hipStream_t)hip_stream);
+    HIPC(hipGetLastError());
+    return RTDM_OK;
+}
+
+// gray + remap + crop of n device frames into the rectifier's planes, then the matcher, chunk by chunk
+static int rgb_chunks(rtdm_bm* bm, rtdm_rectify* rc, int n, const uint8_t* dl, const uint8_t* dr, Plane16W out, hipStream_t s)
+{
+    const size_t fbytes = (size_t)rc->W * rc->H * 3, gframe = rc->gpitch * rc->rh;
+    const int chunk = std::min(bm->laneB, rc->maxB);
+    for (int i0 = 0; i0 < n; i0 += chunk) {
+        const int m = std::min(chunk, n - i0);
+        rectify_gray_launch(rc, dl + (size_t)i0 * fbytes, dr + (size_t)i0 * fbytes, m,
+                            Plane8W{rc->dGray[0], rc->gpitch, gframe}, Plane8W{rc->dGray[1], rc->gpitch, gframe}, s);
+        HIPC(hipGetLastError());
+        const int st = run_chunk(bm, bm->lane[0], m, Plane8{rc->dGray[0], rc->gpitch, gframe}, Plane8{rc->dGray[1], rc->gpitch, gframe},
+                                 rc->rw, rc->rh, Plane16W{out.base + (size_t)i0 * out.frame_e, out.pitch_e, out.frame_e}, s);
+        if (st) return st;
+    }
+    return RTDM_OK;
+}
+
+int rtdm_bm_compute_rgb_device(rtdm_bm* bm, rtdm_rectify* rc, int n, const uint8_t* d_rgb_left,
+                               const uint8_t* d_rgb_right, int16_t* d_disp, void* hip_stream)
+{
+    if (!bm || !rc || !d_rgb_left || !d_rgb_right || !d_disp) return RTDM_ERR_NULL;
+    if (n <= 0) return RTDM_ERR_BAD_SIZE;
+    if (bm->device != rc->device) return RTDM_ERR_BAD_PARAM;
+    int st = check_frame(bm, rc->rw, rc->rh);
+    if (st) return st;
+    HIPC(hipSetDevice(bm->device));
+    const size_t oframe = (size_t)rc->rw * rc->rh;
+    return rgb_chunks(bm, rc, n, d_rgb_left, d_rgb_right, Plane16W{d_disp, (size_t)rc->rw, oframe}, (hipStream_t)hip_stream);
+}
+
+int rtdm_bm_compute_rgb(rtdm_bm* bm, rtdm_rectify* rc, const uint8_t* rgb_left, size_t left_pitch,
+                        const uint8_t* rgb_right, size_t right_pitch, int16_t* disp, size_t disp_pitch)
+{
+    if (!bm || !rc || !rgb_left || !rgb_right || !disp) return RTDM_ERR_NULL;
+    if (bm->device != rc->device) return RTDM_ERR_BAD_PARAM;
+    int st = check_frame(bm, rc->rw, rc->rh);
+    if (st) return st;
+    const size_t row = (size_t)rc->W * 3;
+    if (left_pitch < row || right_pitch < row || disp_pitch < (size_t)rc->rw * 2) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(bm->device));
+    hipStream_t s = bm->stream;
+    st = rectify_upload(rc, rgb_left, left_pitch, rgb_right, right_pitch, s);
+    if (st) return st;
+    const size_t Ws = (size_t)((rc->rw + 7) & ~7);                     // the lane's internal plane (see run_chunk)
+    st = rgb_chunks(bm, rc, 1, rc->dRgb[0], rc->dRgb[1], Plane16W{bm->dOut, Ws, Ws * (size_t)rc->rh}, s);
+    if (st) return st;
+    int16_t* hD = (int16_t*)(bm->hStage + 2 * bm->ppitch * (size_t)bm->maxH);
+    HIPC(hipMemcpyAsync(hD, bm->dOut, Ws * rc->rh * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    for (int y = 0; y < rc->rh; ++y)
+        memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * Ws, (size_t)rc->rw * sizeof(int16_t));
     return RTDM_OK;
 }
 

@@ -147,7 +147,7 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
                     const int den = pp + nn - 2 * m1 + abs(pp - nn);
                     const int v = (D - a - 1 + g.minD) * 256 + (den != 0 ? (pp - nn) * 256 / den : 0) + 15;
                     out = v >> 4;
-                    if (g.want_cost) cost[((size_t)f * g.H + y) * g.W + col] = (uint16_t)m1;
+                    if (g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)m1;
                 }
                 if (g.mask_cols && (col < g.vx0 || col >= g.vx1)) out = g.filtered;
                 db[(size_t)y * disp.pitch_e + col] = (int16_t)out;

@@ -10,6 +10,8 @@ namespace rtdm {
 // Geometry of one StereoBM search, derived once per call on the host.
 struct BMGeom {
     int W, H;            // frame size
+    int Ws;              // row stride (elements) of the per-pixel workspace planes (cost, labels, sizes, run lists,
+                         // head map): W rounded up to 8 so that their rows start 16-byte aligned
     int D, minD;         // numDisparities, minDisparity
     int w, r;            // blockSize, blockSize/2
     int cap, tex, uniq;  // preFilterCap, textureThreshold, uniquenessRatio
@@ -68,8 +70,11 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
 // `newVal`; premerged_rows > 1: that kernel also merged the row pairs inside blocks of that many rows
 // (lrcheck_rows_per_block() for launch_lrcheck).
 void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
-                    int W, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
+                    int W, int Ws, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
                     int y_lo, int y_hi, hipStream_t stream);
+// Ws = row stride of label/size/runs/headmap (>= W)
+// n frames of W x H int16: src -> dst (any pitches)
+void launch_copy16(Plane16W src, Plane16W dst, int W, int H, int n, hipStream_t stream);
 int lrcheck_rows_per_block();
 
 // K5: erode / dilate / dilate / erode with the 10x10 ellipse; tmp = n*W*H bytes scratch.
@@ -95,6 +100,14 @@ size_t depth_scratch_bytes(int max_regions, int maxH);
 void launch_depth_stats(const int16_t* disp, size_t pitch_e, int W, int H, const DepthQ& q, const uint8_t* mask, size_t mpitch,
                         const int* h_regions, int n, int maxH, double unit, void* scratch, double* h_mean, int* h_counts,
                         hipStream_t stream);
+
+// Rectification in front of the matcher (estimator.cpp:29-39).  RectifySrc: n RGB frames, pitch/frame in bytes.
+struct RectifySrc { const uint8_t* base; size_t pitch, frame; };
+void launch_rectify_gray(RectifySrc L, RectifySrc R, const int16_t* map1L, const uint16_t* map2L, const int16_t* map1R,
+                         const uint16_t* map2R, int sW, int sH, int rw, int rh, Plane8W outL, Plane8W outR, int n,
+                         hipStream_t stream);
+void launch_rectify_rgb(RectifySrc S, const int16_t* map1, const uint16_t* map2, int sW, int sH, int rw, int rh, Plane8W out,
+                        int n, hipStream_t stream);
 
 // Synthetic stream generator (bit-identical to synth.py).
 void launch_synth(uint64_t seed, int first_frame, int n, int W, int H, int D, Plane8W L, Plane8W R,

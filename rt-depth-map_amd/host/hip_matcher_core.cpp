@@ -58,6 +58,32 @@ int HIPMatcherCore::computeDepth(const uint8_t* left, size_t leftStep, const uin
     return status_;
 }
 
+HIPRectifierCore::HIPRectifierCore(const int16_t* map1Left, const uint16_t* map2Left, const int16_t* map1Right,
+                                   const uint16_t* map2Right, int rows, int cols, const Rect& roif, int device)
+{
+    status_ = rtdm_rectify_create(map1Left, map2Left, map1Right, map2Right, cols, rows, roif.x, roif.y, roif.width, roif.height,
+                                  1, device, &rc_);
+    if (status_ != RTDM_OK) std::fprintf(stderr, "HIPRectifier: %s\n", rtdm_strerror(status_));
+}
+HIPRectifierCore::~HIPRectifierCore() { rtdm_rectify_destroy(rc_); }
+int HIPRectifierCore::rectifyGray(const uint8_t* rgbLeft, size_t leftStep, const uint8_t* rgbRight, size_t rightStep,
+                                  uint8_t* leftRect, size_t leftRectStep, uint8_t* rightRect, size_t rightRectStep)
+{
+    if (!rc_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    return status_ = rtdm_rectify_gray(rc_, rgbLeft, leftStep, rgbRight, rightStep, leftRect, leftRectStep, rightRect, rightRectStep);
+}
+int HIPRectifierCore::rectifyColour(int which, const uint8_t* rgb, size_t step, uint8_t* out, size_t outStep)
+{
+    if (!rc_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    return status_ = rtdm_rectify_rgb(rc_, which, rgb, step, out, outStep);
+}
+int HIPRectifierCore::compute(HIPMatcherCore& matcher, const uint8_t* rgbLeft, size_t leftStep, const uint8_t* rgbRight,
+                              size_t rightStep, int16_t* out, size_t outStep)
+{
+    if (!rc_ || !matcher.handle()) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    return status_ = rtdm_bm_compute_rgb(matcher.handle(), rc_, rgbLeft, leftStep, rgbRight, rightStep, out, outStep);
+}
+
 HIPSGMCore::HIPSGMCore(int blockSize, int minDisparity, int numOfDisparities, int uniquenessRatio, int speckleWindowSize,
                        int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device)
 {

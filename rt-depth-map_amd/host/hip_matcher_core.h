@@ -78,6 +78,32 @@ private:
     int status_ = RTDM_OK;
 };
 
+// The caller's lines in front of the matcher (/root/reference/estimator.cpp:29-39): cvtColor(RGB2GRAY) + remap with
+// the CV_16SC2 maps of main.cpp:95-96 + crop to roif, for both cameras, on the device.  Not behind an interface in
+// the reference (OpenCV is called inline there), so using it means replacing those lines.
+class HIPRectifierCore {
+public:
+    // map1*: rows x cols x 2 int16, map2*: rows x cols uint16 (continuous Mats: remap_left1.data ...); roif = crop
+    HIPRectifierCore(const int16_t* map1Left, const uint16_t* map2Left, const int16_t* map1Right, const uint16_t* map2Right,
+                     int rows, int cols, const Rect& roif, int device = 0);
+    ~HIPRectifierCore();
+    HIPRectifierCore(const HIPRectifierCore&) = delete;
+    HIPRectifierCore& operator=(const HIPRectifierCore&) = delete;
+    // rgb*: rows x cols x 3 bytes (first channel R); *Rect: roif.height x roif.width bytes
+    int rectifyGray(const uint8_t* rgbLeft, size_t leftStep, const uint8_t* rgbRight, size_t rightStep,
+                    uint8_t* leftRect, size_t leftRectStep, uint8_t* rightRect, size_t rightRectStep);
+    // remap + crop of the colour frame (estimator.cpp:38-39); which = 0: left maps, 1: right maps
+    int rectifyColour(int which, const uint8_t* rgb, size_t step, uint8_t* out, size_t outStep);
+    // estimator.cpp:29-36 + 56 in one call: raw frames in, x16 disparity of the cropped pair out
+    int compute(HIPMatcherCore& matcher, const uint8_t* rgbLeft, size_t leftStep, const uint8_t* rgbRight, size_t rightStep,
+                int16_t* out, size_t outStep);
+    int status() const { return status_; }
+
+private:
+    rtdm_rectify* rc_ = nullptr;
+    int status_ = RTDM_OK;
+};
+
 // VideoFilterDevice counterpart (/root/reference/include/filter/filter.h:13-37,
 // /root/reference/filter/mf-sw.cpp:10-28): owns the frame buffers it hands out.
 class HIPMorphCore {

@@ -19,8 +19,26 @@ int main(int argc, char** argv)
         std::vector<int16_t> out(320 * 240);
         const int c = m.compute(img.data(), 320, img.data(), 320, 240, 320, out.data(), 640);
         std::printf("compute_status=%d\n", c);
-        if (ndev == 0) return (m.status() == RTDM_ERR_NO_DEVICE && c == RTDM_ERR_NO_DEVICE) ? 0 : 1;
-        return (m.status() == RTDM_OK && c == RTDM_OK) ? 0 : 1;
+        // rectifier: identity maps over an 8x6 frame, crop = everything; gray of (r, g, b) = (x, x, x) is x
+        const int RW = 8, RH = 6;
+        std::vector<int16_t> map1((size_t)RW * RH * 2);
+        std::vector<uint16_t> map2((size_t)RW * RH, 0);
+        std::vector<uint8_t> rgb((size_t)RW * RH * 3), gl((size_t)RW * RH), gr((size_t)RW * RH);
+        for (int y = 0; y < RH; ++y)
+            for (int x = 0; x < RW; ++x) {
+                map1[((size_t)y * RW + x) * 2] = (int16_t)x; map1[((size_t)y * RW + x) * 2 + 1] = (int16_t)y;
+                for (int k = 0; k < 3; ++k) rgb[((size_t)y * RW + x) * 3 + k] = (uint8_t)(x * 9 + y);
+            }
+        rtdm::Rect full; full.width = RW; full.height = RH;
+        rtdm::HIPRectifierCore rect(map1.data(), map2.data(), map1.data(), map2.data(), RH, RW, full);
+        const int rs = rect.rectifyGray(rgb.data(), RW * 3, rgb.data(), RW * 3, gl.data(), RW, gr.data(), RW);
+        std::printf("rectifier_status=%d rectify_status=%d\n", rect.status(), rs);
+        if (ndev == 0)
+            return (m.status() == RTDM_ERR_NO_DEVICE && c == RTDM_ERR_NO_DEVICE && rs == RTDM_ERR_NO_DEVICE) ? 0 : 1;
+        bool same = rs == RTDM_OK;
+        for (int y = 0; y < RH && same; ++y)
+            for (int x = 0; x < RW; ++x) same = same && gl[(size_t)y * RW + x] == (uint8_t)(x * 9 + y) && gr[(size_t)y * RW + x] == gl[(size_t)y * RW + x];
+        return (m.status() == RTDM_OK && c == RTDM_OK && same) ? 0 : 1;
     }
     const int W = std::atoi(argv[3]), H = std::atoi(argv[4]), D = std::atoi(argv[5]), w = std::atoi(argv[6]);
     std::vector<uint8_t> in((size_t)2 * W * H);

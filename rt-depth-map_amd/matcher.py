@@ -208,6 +208,73 @@ class HIPMorphologicalFilter:
                                               W, H, stream), "rtdm_morph_run_device")
 
 
+class HIPRectifier:
+    """estimator.cpp:29-39 on the device: RGB -> gray -> remap(INTER_LINEAR, CV_16SC2 maps) -> crop to roif.
+
+    map1_*: HxWx2 int16, map2_*: HxW uint16 (what initUndistortRectifyMap(..., CV_16SC2, ...) returns, main.cpp:95-96);
+    roi = (x, y, w, h) = the reference's roif (main.cpp:80-85)."""
+
+    def __init__(self, map1_left, map2_left, map1_right, map2_right, roi, max_batch=1, device=0):
+        maps = [np.ascontiguousarray(map1_left, np.int16), np.ascontiguousarray(map2_left, np.uint16),
+                np.ascontiguousarray(map1_right, np.int16), np.ascontiguousarray(map2_right, np.uint16)]
+        H, W = maps[1].shape
+        assert maps[0].shape == (H, W, 2) and maps[2].shape == (H, W, 2) and maps[3].shape == (H, W)
+        self.width, self.height, self.roi = W, H, tuple(int(v) for v in roi)
+        self._h = C.c_void_p()
+        B.check(B.lib().rtdm_rectify_create(maps[0].ctypes.data, maps[1].ctypes.data, maps[2].ctypes.data, maps[3].ctypes.data,
+                                            W, H, *self.roi, max_batch, device, C.byref(self._h)), "rtdm_rectify_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            try:
+                B.lib().rtdm_rectify_destroy(self._h)
+            except TypeError:
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def _check_rgb(self, a):
+        assert a.dtype == np.uint8 and a.shape == (self.height, self.width, 3) and a.strides[1] == 3 and a.strides[2] == 1
+
+    def gray(self, rgb_left, rgb_right):
+        """-> (left_rect, right_rect), uint8 roi_h x roi_w each."""
+        self._check_rgb(rgb_left); self._check_rgb(rgb_right)
+        rw, rh = self.roi[2], self.roi[3]
+        l = np.empty((rh, rw), np.uint8); r = np.empty((rh, rw), np.uint8)
+        B.check(B.lib().rtdm_rectify_gray(self._h, rgb_left.ctypes.data, rgb_left.strides[0], rgb_right.ctypes.data,
+                                          rgb_right.strides[0], l.ctypes.data, rw, r.ctypes.data, rw), "rtdm_rectify_gray")
+        return l, r
+
+    def rgb(self, rgb, which=0):
+        """remap + crop of the colour frame with the left (0) or right (1) maps -> roi_h x roi_w x 3."""
+        self._check_rgb(rgb)
+        rw, rh = self.roi[2], self.roi[3]
+        out = np.empty((rh, rw, 3), np.uint8)
+        B.check(B.lib().rtdm_rectify_rgb(self._h, which, rgb.ctypes.data, rgb.strides[0], out.ctypes.data, rw * 3), "rtdm_rectify_rgb")
+        return out
+
+    def gray_device(self, d_rgb_left, d_rgb_right, d_left, d_right, stream=None):
+        """torch uint8 tensors: [n,H,W,3] x2 -> [n,roi_h,roi_w] x2 (contiguous); ordered on `stream` (None = null stream)."""
+        n = d_rgb_left.shape[0]
+        B.check(B.lib().rtdm_rectify_gray_device(self._h, n, d_rgb_left.data_ptr(), d_rgb_right.data_ptr(), d_left.data_ptr(),
+                                                 d_right.data_ptr(), stream), "rtdm_rectify_gray_device")
+
+    def compute(self, matcher, rgb_left, rgb_right):
+        """estimator.cpp:29-36 + 56: raw RGB frames -> x16 disparity of the rectified, cropped pair (host to host)."""
+        self._check_rgb(rgb_left); self._check_rgb(rgb_right)
+        rw, rh = self.roi[2], self.roi[3]
+        disp = np.empty((rh, rw), np.int16)
+        B.check(B.lib().rtdm_bm_compute_rgb(matcher._h, self._h, rgb_left.ctypes.data, rgb_left.strides[0], rgb_right.ctypes.data,
+                                            rgb_right.strides[0], disp.ctypes.data, rw * 2), "rtdm_bm_compute_rgb")
+        return disp
+
+    def compute_device(self, matcher, d_rgb_left, d_rgb_right, d_disp, stream=None):
+        n = d_rgb_left.shape[0]
+        B.check(B.lib().rtdm_bm_compute_rgb_device(matcher._h, self._h, n, d_rgb_left.data_ptr(), d_rgb_right.data_ptr(),
+                                                   d_disp.data_ptr(), stream), "rtdm_bm_compute_rgb_device")
+
+
 def depth_stats_device(d_disp, Q, d_mask, regions, calibration_unit=25.0, device=0, stream=None):
     """torch CUDA tensors: int16 [H,W] x16 disparity, uint8 [H,W] mask -> (mean_cm[n], counts[n]); synchronous."""
     H, W = d_disp.shape

@@ -322,3 +322,71 @@ def depth_stats(disp16, Q, mask, regions, unit=25.0):
         counts.append(c)
         means.append(float(zz[ry:ry + rh, rx:rx + rw][sel].sum() / c * unit / 10.0) if c else 0.0)
     return np.array(means), np.array(counts)
+
+
+# ---- rectification in front of the matcher (independent of oracle/rectify_oracle.c) ---------------------------
+def rgb2gray(rgb):
+    c = rgb.astype(np.int64)
+    return ((c[..., 0] * 4899 + c[..., 1] * 9617 + c[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+def bilinear_table():
+    """The 32x32 table of 2x2 weights the way the library builds it: float products scaled by 2**15, rounded to
+    short, with the fix-up step that forces every 2x2 block to sum to 32768 (never triggered for 5-bit fractions)."""
+    tab = np.zeros((32, 32, 4), np.int32)
+    for fy in range(32):
+        for fx in range(32):
+            ax, ay = np.float32(fx) / np.float32(32), np.float32(fy) / np.float32(32)
+            w = np.array([(1 - ay) * (1 - ax), (1 - ay) * ax, ay * (1 - ax), ay * ax], np.float32)
+            iw = np.rint(w * np.float32(32768)).astype(np.int32)
+            d = int(iw.sum()) - 32768
+            if d < 0:
+                iw[np.argmax(iw)] -= d
+            elif d > 0:
+                iw[np.argmin(iw)] -= d
+            tab[fy, fx] = iw
+    return tab
+
+
+def remap_bilinear(src, map1, map2):
+    """Vectorised, via the table above and zero padding instead of per-sample range checks."""
+    tab = bilinear_table()
+    src3 = src if src.ndim == 3 else src[..., None]
+    sH, sW, cn = src3.shape
+    pad = np.zeros((sH + 2, sW + 2, cn), np.int64)
+    pad[1:-1, 1:-1] = src3
+    sx = map1[..., 0].astype(np.int64); sy = map1[..., 1].astype(np.int64)
+    fx = (map2 & 31).astype(np.int64); fy = ((map2 >> 5) & 31).astype(np.int64)
+    w = tab[fy, fx].astype(np.int64)                                  # dH x dW x 4
+    acc = np.zeros(sx.shape + (cn,), np.int64)
+    for k in range(4):
+        xx = np.clip(sx + (k & 1), -1, sW) + 1
+        yy = np.clip(sy + (k >> 1), -1, sH) + 1
+        acc += w[..., k, None] * pad[yy, xx]
+    out = ((acc + (1 << 14)) >> 15).astype(np.uint8)
+    return out if src.ndim == 3 else out[..., 0]
+
+
+def init_undistort_rectify_map(M, D, R, P, W, H):
+    """Closed-form rays (no running sums along the row), numpy.linalg.inv: an ulp-level different route to the
+    same maps; entries may differ from the oracle's where u*32 lands within an ulp of a rounding boundary."""
+    M = np.asarray(M, np.float64).reshape(3, 3); R = np.asarray(R, np.float64).reshape(3, 3)
+    P = np.asarray(P, np.float64).reshape(3, 4)
+    d = np.zeros(14); dd = np.asarray(D, np.float64).reshape(-1); d[:len(dd)] = dd
+    k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4 = d[:12]
+    ir = np.linalg.inv(P[:, :3] @ R)
+    j, i = np.meshgrid(np.arange(W, dtype=np.float64), np.arange(H, dtype=np.float64))
+    X = ir[0, 0] * j + ir[0, 1] * i + ir[0, 2]
+    Y = ir[1, 0] * j + ir[1, 1] * i + ir[1, 2]
+    Wd = ir[2, 0] * j + ir[2, 1] * i + ir[2, 2]
+    x, y = X / Wd, Y / Wd
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2
+    kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2)
+    xd = x * kr + p1 * 2 * x * y + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * 2 * x * y + s3 * r2 + s4 * r2 * r2
+    u = M[0, 0] * xd + M[0, 2]; v = M[1, 1] * yd + M[1, 2]
+    iu = np.rint(u * 32).astype(np.int64); iv = np.rint(v * 32).astype(np.int64)
+    map1 = np.stack([iu >> 5, iv >> 5], -1).astype(np.int16)
+    map2 = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
+    return map1, map2

@@ -1,0 +1,39 @@
+"""Shared inputs of the rectification tests: the reference's calibration numbers (tests/golden/calib.json, data
+extracted from /root/reference/backup/*/{intrinsics,extrinsics}.yml by tests/golden/make_calib.py), the crop the
+reference derives from them (main.cpp:80-85) and a synthetic RGB sensor frame."""
+import json
+import os
+
+import numpy as np
+
+_CAL = None
+
+
+def calib(res):
+    global _CAL
+    if _CAL is None:
+        _CAL = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "calib.json")))
+    c = _CAL[res]
+    m = lambda k: np.array(c[k]["data"], np.float64).reshape(c[k]["rows"], c[k]["cols"])  # noqa: E731
+    out = {k: m(k) for k in ("M1", "D1", "M2", "D2", "R1", "R2", "P1", "P2", "Q")}
+    out["W"], out["H"] = int(c["Width"]), int(c["Height"])
+    r1, r2 = c["ROI1"], c["ROI2"]
+    # roif (main.cpp:80-85): max of the origins, min of the sizes
+    out["roi"] = (max(r1[0], r2[0]), max(r1[1], r2[1]), min(r1[2], r2[2]), min(r1[3], r2[3]))
+    return out
+
+
+def maps(oracle, res):
+    c = calib(res)
+    l1, l2 = oracle.init_undistort_rectify_map(c["M1"], c["D1"], c["R1"], c["P1"], c["W"], c["H"])
+    r1, r2 = oracle.init_undistort_rectify_map(c["M2"], c["D2"], c["R2"], c["P2"], c["W"], c["H"])
+    return c, (l1, l2, r1, r2)
+
+
+def rgb_pair(synth, seed, W, H):
+    """Two textured RGB frames (channels = differently seeded noise images)."""
+    a, b = synth.make_pair(synth.STREAM_SEED + 5000 + seed, W, H, 16)
+    c, d = synth.make_pair(synth.STREAM_SEED + 5100 + seed, W, H, 16)
+    left = np.ascontiguousarray(np.stack([a, c, ((a.astype(np.int32) + d) // 2).astype(np.uint8)], -1))
+    right = np.ascontiguousarray(np.stack([b, d, ((b.astype(np.int32) + c) // 2).astype(np.uint8)], -1))
+    return left, right

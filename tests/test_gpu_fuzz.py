@@ -114,6 +114,24 @@ def test_extreme_shapes(pkg, oracle, synth, W, H, D, w):
     assert np.array_equal(got, oracle.bm_compute(L, R, numDisparities=D, blockSize=w, nthreads=8)), (W, H, D, w)
 
 
+@pytest.mark.parametrize("W,H", [(328, 200), (333, 201), (336, 57), (1288, 64)])
+def test_device_tensors_of_every_alignment_class(pkg, oracle, synth, W, H):
+    # contiguous device tensors: W % 16 == 0 takes the 128-bit row kernels, W % 8 == 0 the 64-bit prefilter,
+    # anything else the byte-wise prefilter / scalar left-right check / unvectorised speckle merge
+    import torch
+    n, D, w = 3, 32, 7
+    L, R = synth.make_stream(77 + W, n, W, H, D)
+    dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n)
+    m.compute_device(dL, dR, dD, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dD.cpu().numpy()
+    m.close()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.bm_compute(L[i], R[i], numDisparities=D, blockSize=w, nthreads=8)), (W, H, i)
+
+
 def test_too_wide_is_refused_not_crashed(pkg):
     with pytest.raises(pkg.binding.RtdmError) as e:
         pkg.HIPMatcher(numOfDisparities=64, blockSize=9, width=4097, height=32)
