@@ -202,6 +202,30 @@ int rtdm_bm_compute_rgb(rtdm_bm* bm, rtdm_rectify* rc, const uint8_t* rgb_left, 
 int rtdm_bm_compute_rgb_device(rtdm_bm* bm, rtdm_rectify* rc, int n, const uint8_t* d_rgb_left,
                                const uint8_t* d_rgb_right, int16_t* d_disp, void* hip_stream);
 
+/* ---- the object detection that yields the matcher's ROI ---------------
+ * rtdm_objects_detect <- estimator.cpp:40-53: cvtColor(RGB2BGR) + cvtColor(BGR2HSV) + inRange(low, high) -> filter_in;
+ *                        morphFilter->run(filter_in, filter_out); findContours(RETR_EXTERNAL) + boundingRect per contour,
+ *                        boxes below min_area dropped (fill_bounding_rects_of_contours, estimator.cpp:167-174); roi = union
+ *                        of the boxes (find_relevant_matching_region, estimator.cpp:176-204).  rgb = the rectified colour
+ *                        crop (height x width x 3, R first).  boxes come in the order of the reference's obj_boundings;
+ *                        *nboxes = how many there are (only max_boxes are stored).  zero_border = 1 restates
+ *                        OpenCV <= 3.1's findContours, which clears the outermost rows/columns first; 0 = OpenCV >= 3.2.
+ * rtdm_estimate_frame <- one iteration of Estimator::run without capture, decode and drawing (estimator.cpp:29-77):
+ *                        raw RGB frames in, per object the box, mean Z [cm] and pixel count out.  Everything between
+ *                        stays in HBM; one small read-back (the boxes) decides the matcher's ROI1.  If no box survives
+ *                        the matcher is skipped (*nboxes = 0).  At most RTDM_MAX_REGIONS objects get a depth. */
+typedef struct rtdm_objects rtdm_objects;
+typedef struct rtdm_hsv_range { int low[3], high[3]; } rtdm_hsv_range;   /* H, S, V inclusive; estimator.cpp:110-115: {0,150,0}..{9,255,255} */
+int rtdm_objects_create(int width, int height, int device, rtdm_objects** out);
+void rtdm_objects_destroy(rtdm_objects* ob);
+int rtdm_objects_detect(rtdm_objects* ob, const uint8_t* rgb, size_t pitch, const rtdm_hsv_range* range, int min_area,
+                        int zero_border, uint8_t* mask_out, size_t mask_pitch, rtdm_region* boxes, int max_boxes,
+                        int* nboxes, rtdm_region* roi);
+int rtdm_estimate_frame(rtdm_bm* bm, rtdm_rectify* rc, rtdm_objects* ob, const uint8_t* rgb_left, size_t left_pitch,
+                        const uint8_t* rgb_right, size_t right_pitch, const double* Q, const rtdm_hsv_range* range,
+                        int min_area, int zero_border, double calibration_unit, rtdm_region* boxes, double* mean_cm,
+                        int* counts, int max_boxes, int* nboxes, int16_t* disp, size_t disp_pitch);
+
 /* ---- synthetic rectified-pair stream (stands in for stream/ + decoder/, which are out of
  * scope): frame f of the stream uses seed + f; bit-identical to rt-depth-map_amd/synth.py. */
 int rtdm_synth_pairs_device(uint64_t seed, int first_frame, int n, int width, int height,

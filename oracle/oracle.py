@@ -91,6 +91,14 @@ def lib():
             getattr(L, n).restype = C.c_int
         L.orc_init_undistort_rectify_map.argtypes = [dp, dp, dp, dp, C.c_int, C.c_int, i16p, u16p]
         L.orc_init_undistort_rectify_map.restype = C.c_int
+        L.orc_rgb2hsv.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, u8p, C.c_size_t]
+        L.orc_rgb2hsv.restype = None
+        L.orc_hsv_inrange.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, ip, ip, u8p, C.c_size_t]
+        L.orc_hsv_inrange.restype = None
+        L.orc_external_boxes.argtypes = [u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, ip, C.c_int]
+        L.orc_external_boxes.restype = C.c_int
+        L.orc_union_box.argtypes = [ip, C.c_int, ip]
+        L.orc_union_box.restype = None
         _lib = L
     return _lib
 
@@ -293,3 +301,38 @@ def init_undistort_rectify_map(M, D, R, P, W, H):
     if rc != 0:
         raise ValueError("orc_init_undistort_rectify_map failed: %d" % rc)
     return map1, map2
+
+
+# ---- object detection -> ROI (objects_oracle.c) ---------------------------------------------------------------
+HSV_LOW, HSV_HIGH = (0, 150, 0), (9, 255, 255)          # estimator.cpp:110-115
+
+
+def rgb2hsv(rgb):
+    rgb = np.ascontiguousarray(rgb, np.uint8); H, W, _ = rgb.shape
+    out = np.empty_like(rgb)
+    lib().orc_rgb2hsv(_p(rgb, C.c_uint8), W * 3, W, H, _p(out, C.c_uint8), W * 3)
+    return out
+
+
+def hsv_inrange(rgb, lo=HSV_LOW, hi=HSV_HIGH):
+    rgb = np.ascontiguousarray(rgb, np.uint8); H, W, _ = rgb.shape
+    out = np.empty((H, W), np.uint8)
+    lib().orc_hsv_inrange(_p(rgb, C.c_uint8), W * 3, W, H, (C.c_int * 3)(*lo), (C.c_int * 3)(*hi), _p(out, C.c_uint8), W)
+    return out
+
+
+def external_boxes(mask, min_area=100, zero_border=True, max_boxes=4096):
+    """-> list of (x, y, w, h) in the order of the reference's obj_boundings."""
+    mask = np.ascontiguousarray(mask, np.uint8); H, W = mask.shape
+    boxes = np.zeros((max_boxes, 4), np.int32)
+    n = lib().orc_external_boxes(_p(mask, C.c_uint8), W, W, H, int(zero_border), min_area, _p(boxes, C.c_int), max_boxes)
+    if n < 0:
+        raise ValueError("orc_external_boxes failed: %d" % n)
+    return [tuple(int(v) for v in b) for b in boxes[:min(n, max_boxes)]]
+
+
+def union_box(boxes):
+    b = np.ascontiguousarray(boxes, np.int32).reshape(-1, 4)
+    roi = (C.c_int * 4)()
+    lib().orc_union_box(_p(b, C.c_int), len(b), roi)
+    return tuple(roi)

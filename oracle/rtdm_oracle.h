@@ -133,6 +133,15 @@ int orc_rectify_rgb(const uint8_t* rgb, size_t sstep, int W, int H, const int16_
 int orc_init_undistort_rectify_map(const double M[9], const double D[14], const double R[9], const double P[12],
                                    int W, int H, int16_t* map1, uint16_t* map2);
 
+/* ---- object detection that produces the matcher's ROI (defined in objects_oracle.c) ----
+ * rgb: H x W x 3, first channel R (the rectified colour crop).  lo/hi: inclusive H, S, V bounds (estimator.cpp:110-115).
+ * boxes: (x, y, width, height) of the external 8-connected components with area >= min_area, in the order of the
+ * reference's obj_boundings; orc_external_boxes returns how many there are (only max_boxes are stored). */
+void orc_rgb2hsv(const uint8_t* rgb, size_t sstep, int W, int H, uint8_t* hsv, size_t dstep);
+void orc_hsv_inrange(const uint8_t* rgb, size_t sstep, int W, int H, const int lo[3], const int hi[3], uint8_t* mask, size_t mstep);
+int orc_external_boxes(const uint8_t* mask, size_t mstep, int W, int H, int zero_border, int min_area, int* boxes, int max_boxes);
+void orc_union_box(const int* boxes, int n, int roi[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,5 +6,5 @@ The compute path is the HIP library rt-depth-map_amd/lib/librtdm_hip.so (C ABI: 
 nothing in this package falls back to the CPU.
 """
 from . import binding, synth  # noqa: F401
-from .matcher import (HIPMatcher, HIPMorphologicalFilter, HIPRectifier, HIPSemiGlobalMatcher,  # noqa: F401
-                      depth_stats_device, synth_pairs_device)
+from .matcher import (HIPMatcher, HIPMorphologicalFilter, HIPObjectDetector, HIPRectifier,  # noqa: F401
+                      HIPSemiGlobalMatcher, depth_stats_device, estimate_frame, synth_pairs_device)

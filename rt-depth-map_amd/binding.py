@@ -26,6 +26,10 @@ class Region(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("x", "y", "width", "height")]
 
 
+class HsvRange(C.Structure):
+    _fields_ = [("low", C.c_int * 3), ("high", C.c_int * 3)]
+
+
 class SGMParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("blockSize", "minDisparity", "numDisparities", "P1", "P2", "uniquenessRatio",
                                        "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
@@ -90,6 +94,13 @@ def lib():
         "rtdm_rectify_gray_device": (C.c_int, [vp, C.c_int, u8p, u8p, u8p, u8p, vp]),
         "rtdm_bm_compute_rgb": (C.c_int, [vp, vp, u8p, sz, u8p, sz, i16p, sz]),
         "rtdm_bm_compute_rgb_device": (C.c_int, [vp, vp, C.c_int, u8p, u8p, i16p, vp]),
+        "rtdm_objects_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+        "rtdm_objects_destroy": (None, [vp]),
+        "rtdm_objects_detect": (C.c_int, [vp, u8p, sz, C.POINTER(HsvRange), C.c_int, C.c_int, u8p, sz, C.POINTER(Region), C.c_int,
+                                          C.POINTER(C.c_int), C.POINTER(Region)]),
+        "rtdm_estimate_frame": (C.c_int, [vp, vp, vp, u8p, sz, u8p, sz, C.POINTER(C.c_double), C.POINTER(HsvRange), C.c_int, C.c_int,
+                                          C.c_double, C.POINTER(Region), C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_int,
+                                          C.POINTER(C.c_int), i16p, sz]),
         "rtdm_synth_pairs_device": (C.c_int, [C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u8p, u8p,
                                               sz, sz, C.c_int, vp]),
     }
@@ -108,7 +119,8 @@ EXPORTS = ("rtdm_strerror rtdm_last_hip_error rtdm_abi_version rtdm_device_count
            "rtdm_morph_run_device rtdm_synth_pairs_device rtdm_sgm_default_params rtdm_sgm_create rtdm_sgm_destroy "
            "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_bm_compute_depth rtdm_depth_stats_device "
            "rtdm_rectify_create rtdm_rectify_destroy rtdm_rectify_gray rtdm_rectify_rgb rtdm_rectify_gray_device "
-           "rtdm_bm_compute_rgb rtdm_bm_compute_rgb_device").split()
+           "rtdm_bm_compute_rgb rtdm_bm_compute_rgb_device rtdm_objects_create rtdm_objects_destroy rtdm_objects_detect "
+           "rtdm_estimate_frame").split()
 
 
 def check(status, where):

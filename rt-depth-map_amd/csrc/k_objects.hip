@@ -1,0 +1,145 @@
+// k_objects.hip -- the object detection that produces the matcher's ROI, on the device:
+//     cvtColor(BGR2HSV) + inRange                     (/root/reference/estimator.cpp:40-43)   -> k_hsv_inrange
+//     [morphFilter->run: k_morph.hip]                 (estimator.cpp:45)
+//     findContours(RETR_EXTERNAL) + boundingRect      (estimator.cpp:47, 167-174)             -> k_cc_*
+// Semantics: oracle/objects_oracle.c.  Connected components by union-find over one label plane: foreground pixels
+// are united 8-connected, background pixels 4-connected, background on the image border with a virtual frame node
+// (index W*H).  Roots are the smallest index of a set = the component's first pixel in raster order, which is what
+// decides both the contour order and (through the background left of it) whether the component is external.
+#include "rtdm_kernels.h"
+#include "rtdm_device.h"
+
+namespace rtdm {
+
+struct HsvTabs { int sdiv[256], hdiv[256]; };
+static __device__ HsvTabs g_hsv;
+
+__global__ void k_hsv_tabs()
+{
+    const int i = threadIdx.x;
+    // round(255*4096 / i), round(180*4096 / (6 i)): exact in integers (no quotient is a tie)
+    g_hsv.sdiv[i] = i ? ((255 << 12) * 2 + i) / (2 * i) : 0;
+    g_hsv.hdiv[i] = i ? ((180 << 12) * 2 + 6 * i) / (12 * i) : 0;
+}
+
+__global__ __launch_bounds__(256) void k_hsv_inrange(const uint8_t* rgb, size_t pitch, int W, int H, int lh, int ls, int lv,
+                                                     int hh, int hs, int hv, uint8_t* mask, size_t mpitch)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= W * H) return;
+    const int y = idx / W, x = idx - y * W;
+    const uint8_t* p = rgb + (size_t)y * pitch + (size_t)x * 3;
+    const int r = p[0], g = p[1], b = p[2];
+    const int v = max(r, max(g, b)), vmin = min(r, min(g, b)), diff = v - vmin;
+    const int s = (diff * g_hsv.sdiv[v] + (1 << 11)) >> 12;
+    int h = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+    h = (h * g_hsv.hdiv[diff] + (1 << 11)) >> 12;
+    if (h < 0) h += 180;
+    h = min(max(h, 0), 255);
+    const bool ok = h >= lh && h <= hh && s >= ls && s <= hs && v >= lv && v <= hv;
+    mask[(size_t)y * mpitch + x] = ok ? 255 : 0;
+}
+
+__device__ __forceinline__ bool cc_fg(const uint8_t* mask, size_t mpitch, int W, int H, int x, int y, int zero_border)
+{
+    if (zero_border && (x == 0 || y == 0 || x == W - 1 || y == H - 1)) return false;
+    return mask[(size_t)y * mpitch + x] != 0;
+}
+
+__global__ __launch_bounds__(256) void k_cc_init(int32_t* label, int4* box, int W, int N, int* count)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p > N) return;
+    label[p] = p;
+    if (p < N) { const int y = p / W, x = p - y * W; box[p] = make_int4(x, y, x, y); }
+    if (p == 0) *count = 0;
+}
+
+__global__ __launch_bounds__(256) void k_cc_merge(const uint8_t* mask, size_t mpitch, int32_t* label, int W, int H, int zero_border)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= W * H) return;
+    const int y = p / W, x = p - y * W;
+    const bool v = cc_fg(mask, mpitch, W, H, x, y, zero_border);
+    if (v) {
+        if (x > 0 && cc_fg(mask, mpitch, W, H, x - 1, y, zero_border)) uf_union(label, p, p - 1);
+        if (y > 0) {
+            const bool up = cc_fg(mask, mpitch, W, H, x, y - 1, zero_border);
+            if (up) uf_union(label, p, p - W);
+            // the diagonals are implied by `up` together with the row-wise unions of the row above
+            if (!up && x > 0 && cc_fg(mask, mpitch, W, H, x - 1, y - 1, zero_border)) uf_union(label, p, p - W - 1);
+            if (!up && x + 1 < W && cc_fg(mask, mpitch, W, H, x + 1, y - 1, zero_border)) uf_union(label, p, p - W + 1);
+        }
+    } else {
+        if (x > 0 && !cc_fg(mask, mpitch, W, H, x - 1, y, zero_border)) uf_union(label, p, p - 1);
+        if (y > 0 && !cc_fg(mask, mpitch, W, H, x, y - 1, zero_border)) uf_union(label, p, p - W);
+        if (x == 0 || y == 0 || x == W - 1 || y == H - 1) uf_union(label, p, W * H);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cc_bbox(const uint8_t* mask, size_t mpitch, int32_t* label, int4* box, int W, int H, int zero_border)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= W * H) return;
+    const int y = p / W, x = p - y * W;
+    if (!cc_fg(mask, mpitch, W, H, x, y, zero_border)) return;
+    const int r = uf_find(label, p);
+    if (r == p) return;                                  // the root's own coordinates are its initial box
+    int* b = (int*)&box[r];
+    atomicMin(b + 0, x); atomicMin(b + 1, y); atomicMax(b + 2, x); atomicMax(b + 3, y);
+}
+
+// one record per foreground root: first pixel, box, external flag
+__global__ __launch_bounds__(256) void k_cc_collect(const uint8_t* mask, size_t mpitch, int32_t* label, const int4* box, int W, int H,
+                                                    int zero_border, int* count, int* records, int max_records)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= W * H) return;
+    const int y = p / W, x = p - y * W;
+    if (!cc_fg(mask, mpitch, W, H, x, y, zero_border) || ld_relaxed(&label[p]) != p) return;
+    const bool external = x == 0 || uf_find(label, p - 1) == uf_find(label, W * H);
+    const int slot = atomicAdd(count, 1);
+    if (slot >= max_records) return;
+    const int4 b = box[p];
+    int* r = records + 6 * slot;
+    r[0] = p; r[1] = b.x; r[2] = b.y; r[3] = b.z - b.x + 1; r[4] = b.w - b.y + 1; r[5] = external ? 1 : 0;
+}
+
+void launch_hsv_inrange(const uint8_t* rgb, size_t pitch, int W, int H, const int lo[3], const int hi[3], uint8_t* mask,
+                        size_t mpitch, hipStream_t stream)
+{
+    static bool tabs[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !tabs[dev]) {            // once per device, finished before anything can use the tables
+        hipLaunchKernelGGL(k_hsv_tabs, dim3(1), dim3(256), 0, stream);
+        (void)hipStreamSynchronize(stream);
+        tabs[dev] = true;
+    }
+    hipLaunchKernelGGL(k_hsv_inrange, dim3((W * H + 255) / 256), dim3(256), 0, stream, rgb, pitch, W, H, lo[0], lo[1], lo[2],
+                       hi[0], hi[1], hi[2], mask, mpitch);
+}
+
+size_t cc_scratch_bytes(int W, int H, int max_records)
+{ return ((size_t)W * H + 1) * 4 + 64 + (size_t)W * H * 16 + 64 + (size_t)max_records * 24 + 64; }
+
+// label: W*H+1 ints, box: W*H int4, count: 1 int, records: max_records x 6 ints -- all carved out of `scratch`.
+// On return the kernels are enqueued; *d_count / *d_records point at the results inside scratch.
+void launch_cc_boxes(const uint8_t* mask, size_t mpitch, int W, int H, int zero_border, void* scratch, int max_records,
+                     int** d_count, int** d_records, hipStream_t stream)
+{
+    const int N = W * H;
+    uint8_t* s = (uint8_t*)scratch;
+    int4* box = (int4*)s;                         s += (size_t)N * 16 + 64;
+    int32_t* label = (int32_t*)s;                 s += (((size_t)N + 1) * 4 + 63) & ~(size_t)63;
+    int* records = (int*)s;                       s += (size_t)max_records * 24;
+    int* count = (int*)s;
+    const dim3 grid((N + 1 + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_cc_init, grid, block, 0, stream, label, box, W, N, count);
+    hipLaunchKernelGGL(k_cc_merge, grid, block, 0, stream, mask, mpitch, label, W, H, zero_border);
+    hipLaunchKernelGGL(k_cc_bbox, grid, block, 0, stream, mask, mpitch, label, box, W, H, zero_border);
+    hipLaunchKernelGGL(k_cc_collect, grid, block, 0, stream, mask, mpitch, label, box, W, H, zero_border, count, records, max_records);
+    *d_count = count; *d_records = records;
+}
+
+}  // namespace rtdm

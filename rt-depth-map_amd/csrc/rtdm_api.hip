@@ -1012,6 +1012,170 @@ int rtdm_bm_compute_rgb(rtdm_bm* bm, rtdm_rectify* rc, const uint8_t* rgb_left, 
     return RTDM_OK;
 }
 
+// ---- object detection -> ROI (estimator.cpp:40-53) and the whole per-frame chain ---------------------------------
+struct rtdm_objects {
+    int W, H, device, maxRec;
+    uint8_t *dRgb, *dMaskIn, *dMaskOut, *dT0, *dT1;
+    void* dScratch;
+    int* hRec;                    // pinned: [0] = count, then the first HEAD records
+    std::vector<int> all;         // host copy of every record when there are more than HEAD
+    hipStream_t stream;
+};
+static const int OBJ_HEAD = 512;  // records fetched together with the count
+
+void rtdm_objects_destroy(rtdm_objects* ob)
+{
+    if (!ob) return;
+    (void)hipSetDevice(ob->device);
+    if (ob->stream) (void)hipStreamSynchronize(ob->stream);
+    void* bufs[] = {ob->dRgb, ob->dMaskIn, ob->dMaskOut, ob->dT0, ob->dT1, ob->dScratch};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (ob->hRec) (void)hipHostFree(ob->hRec);
+    if (ob->stream) (void)hipStreamDestroy(ob->stream);
+    delete ob;
+}
+
+int rtdm_objects_create(int width, int height, int device, rtdm_objects** out)
+{
+    if (!out) return RTDM_ERR_NULL;
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || width > 32767 || height > 32767 || (long)width * height >= (1L << 30)) return RTDM_ERR_BAD_SIZE;
+    int st = use_device(device);
+    if (st) return st;
+    rtdm_objects* ob = new (std::nothrow) rtdm_objects();
+    if (!ob) return RTDM_ERR_NOMEM;
+    ob->W = width; ob->H = height; ob->device = device;
+    ob->maxRec = ((width + 1) / 2 + 1) * ((height + 1) / 2 + 1);          // more 8-connected components cannot exist
+    const size_t px = (size_t)width * height;
+    hipError_t e = hipStreamCreateWithFlags(&ob->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&ob->dRgb, px * 3 + 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&ob->dMaskIn, px);
+    if (e == hipSuccess) e = hipMalloc((void**)&ob->dMaskOut, px);
+    if (e == hipSuccess) e = hipMalloc((void**)&ob->dT0, px);
+    if (e == hipSuccess) e = hipMalloc((void**)&ob->dT1, px);
+    if (e == hipSuccess) e = hipMalloc(&ob->dScratch, cc_scratch_bytes(width, height, ob->maxRec));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ob->hRec, (size_t)(1 + 6 * OBJ_HEAD) * sizeof(int) + px * 3, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        g_hip_err = std::string("rtdm_objects_create: ") + hipGetErrorString(e);
+        rtdm_objects_destroy(ob);
+        return e == hipErrorOutOfMemory ? RTDM_ERR_NOMEM : RTDM_ERR_HIP;
+    }
+    *out = ob;
+    return RTDM_OK;
+}
+
+// dRgb (crop, pitch 3W) -> mask -> morphology -> component boxes; synchronises `s` to read the boxes back.
+static int objects_run(rtdm_objects* ob, const rtdm_hsv_range* range, int min_area, int zero_border, rtdm_region* boxes,
+                       int max_boxes, int* nboxes, rtdm_region* roi, hipStream_t s)
+{
+    const int W = ob->W, H = ob->H;
+    launch_hsv_inrange(ob->dRgb, (size_t)W * 3, W, H, range->low, range->high, ob->dMaskIn, (size_t)W, s);
+    launch_morph_open_close(Plane8{ob->dMaskIn, (size_t)W, (size_t)W * H}, Plane8W{ob->dMaskOut, (size_t)W, (size_t)W * H},
+                            ob->dT0, ob->dT1, W, H, 1, s);
+    int *dCount = nullptr, *dRec = nullptr;
+    launch_cc_boxes(ob->dMaskOut, (size_t)W, W, H, zero_border, ob->dScratch, ob->maxRec, &dCount, &dRec, s);
+    HIPC(hipGetLastError());
+    HIPC(hipMemcpyAsync(ob->hRec, dCount, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(ob->hRec + 1, dRec, (size_t)6 * std::min(OBJ_HEAD, ob->maxRec) * sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    const int nrec = std::min(ob->hRec[0], ob->maxRec);
+    const int* rec = ob->hRec + 1;
+    if (nrec > OBJ_HEAD) {
+        ob->all.resize((size_t)6 * nrec);
+        HIPC(hipMemcpy(ob->all.data(), dRec, (size_t)6 * nrec * sizeof(int), hipMemcpyDeviceToHost));
+        rec = ob->all.data();
+    }
+    // reverse discovery order = descending first-pixel index; external components with area >= min_area only
+    std::vector<const int*> keep;
+    for (int i = 0; i < nrec; ++i) {
+        const int* r = rec + 6 * i;
+        if (r[5] && r[3] * r[4] >= min_area) keep.push_back(r);
+    }
+    std::sort(keep.begin(), keep.end(), [](const int* a, const int* b) { return a[0] > b[0]; });
+    int max_x = -1000000, max_y = -1000000, min_x = 1000000, min_y = 1000000;
+    for (size_t i = 0; i < keep.size(); ++i) {
+        const int* r = keep[i];
+        if ((int)i < max_boxes && boxes) { boxes[i].x = r[1]; boxes[i].y = r[2]; boxes[i].width = r[3]; boxes[i].height = r[4]; }
+        min_x = std::min(min_x, r[1]); min_y = std::min(min_y, r[2]);
+        max_x = std::max(max_x, r[1] + r[3]); max_y = std::max(max_y, r[2] + r[4]);
+    }
+    *nboxes = (int)keep.size();
+    if (roi) { roi->x = min_x; roi->y = min_y; roi->width = max_x - min_x; roi->height = max_y - min_y; }
+    return RTDM_OK;
+}
+
+int rtdm_objects_detect(rtdm_objects* ob, const uint8_t* rgb, size_t pitch, const rtdm_hsv_range* range, int min_area,
+                        int zero_border, uint8_t* mask_out, size_t mask_pitch, rtdm_region* boxes, int max_boxes,
+                        int* nboxes, rtdm_region* roi)
+{
+    if (!ob || !rgb || !range || !nboxes || (max_boxes > 0 && !boxes)) return RTDM_ERR_NULL;
+    const size_t row = (size_t)ob->W * 3;
+    if (pitch < row || max_boxes < 0 || (mask_out && mask_pitch < (size_t)ob->W)) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(ob->device));
+    hipStream_t s = ob->stream;
+    uint8_t* h = (uint8_t*)(ob->hRec + 1 + 6 * OBJ_HEAD);
+    for (int y = 0; y < ob->H; ++y) memcpy(h + (size_t)y * row, rgb + (size_t)y * pitch, row);
+    HIPC(hipMemcpyAsync(ob->dRgb, h, row * ob->H, hipMemcpyHostToDevice, s));
+    int st = objects_run(ob, range, min_area, zero_border, boxes, max_boxes, nboxes, roi, s);
+    if (st) return st;
+    if (mask_out) {
+        HIPC(hipMemcpy2DAsync(mask_out, mask_pitch, ob->dMaskOut, (size_t)ob->W, (size_t)ob->W, ob->H, hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+    }
+    return RTDM_OK;
+}
+
+int rtdm_estimate_frame(rtdm_bm* bm, rtdm_rectify* rc, rtdm_objects* ob, const uint8_t* rgb_left, size_t left_pitch,
+                        const uint8_t* rgb_right, size_t right_pitch, const double* Q, const rtdm_hsv_range* range,
+                        int min_area, int zero_border, double calibration_unit, rtdm_region* boxes, double* mean_cm,
+                        int* counts, int max_boxes, int* nboxes, int16_t* disp, size_t disp_pitch)
+{
+    if (!bm || !rc || !ob || !rgb_left || !rgb_right || !Q || !range || !boxes || !mean_cm || !counts || !nboxes) return RTDM_ERR_NULL;
+    if (bm->device != rc->device || bm->device != ob->device) return RTDM_ERR_BAD_PARAM;
+    if (ob->W != rc->rw || ob->H != rc->rh || max_boxes <= 0) return RTDM_ERR_BAD_SIZE;
+    int st = check_frame(bm, rc->rw, rc->rh);
+    if (st) return st;
+    const int W = rc->rw, H = rc->rh;
+    const size_t row = (size_t)rc->W * 3, fbytes = row * rc->H;
+    if (left_pitch < row || right_pitch < row || (disp && disp_pitch < (size_t)W * 2)) return RTDM_ERR_BAD_SIZE;
+    HIPC(hipSetDevice(bm->device));
+    hipStream_t s = bm->stream;
+    st = rectify_upload(rc, rgb_left, left_pitch, rgb_right, right_pitch, s);
+    if (st) return st;
+    // estimator.cpp:29-39: both gray crops and the colour crop of the left frame
+    const size_t gframe = rc->gpitch * H;
+    rectify_gray_launch(rc, rc->dRgb[0], rc->dRgb[1], 1, Plane8W{rc->dGray[0], rc->gpitch, gframe}, Plane8W{rc->dGray[1], rc->gpitch, gframe}, s);
+    launch_rectify_rgb(RectifySrc{rc->dRgb[0], row, fbytes}, rc->dMap1[0], rc->dMap2[0], rc->W, rc->H, W, H,
+                       Plane8W{ob->dRgb, (size_t)W * 3, (size_t)W * 3 * H}, 1, s);
+    // estimator.cpp:40-53
+    rtdm_region roi;
+    st = objects_run(ob, range, min_area, zero_border, boxes, max_boxes, nboxes, &roi, s);
+    if (st) return st;
+    if (*nboxes == 0) return RTDM_OK;                     // estimator.cpp:48: nothing to measure in this frame
+    const int nreg = std::min(std::min(*nboxes, max_boxes), RTDM_MAX_REGIONS);
+    // estimator.cpp:54-56
+    st = rtdm_bm_set_roi(bm, 1, roi.x, roi.y, roi.width, roi.height);
+    if (st) return st;
+    const size_t Ws = (size_t)((W + 7) & ~7);
+    st = run_chunk(bm, bm->lane[0], 1, Plane8{rc->dGray[0], rc->gpitch, gframe}, Plane8{rc->dGray[1], rc->gpitch, gframe}, W, H,
+                   Plane16W{bm->dOut, Ws, Ws * (size_t)H}, s);
+    if (st) return st;
+    // estimator.cpp:75-77
+    int flat[4 * RTDM_MAX_REGIONS], maxh = 1;
+    st = check_regions(boxes, nreg, W, H, flat, &maxh);
+    if (st) return st;
+    DepthQ q; std::copy(Q, Q + 16, q.q);
+    launch_depth_stats(bm->dOut, Ws, W, H, q, ob->dMaskOut, (size_t)W, flat, nreg, bm->maxH, calibration_unit, bm->dDepth,
+                       mean_cm, counts, s);
+    int16_t* hD = (int16_t*)(bm->hStage + 2 * bm->ppitch * (size_t)bm->maxH);
+    if (disp) HIPC(hipMemcpyAsync(hD, bm->dOut, Ws * H * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(s));
+    if (disp)
+        for (int y = 0; y < H; ++y) memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * Ws, (size_t)W * sizeof(int16_t));
+    return RTDM_OK;
+}
+
 // ---- synthetic stream ------------------------------------------------------------------------
 int rtdm_synth_pairs_device(uint64_t seed, int first_frame, int n, int width, int height, int numDisparities,
                             uint8_t* d_left, uint8_t* d_right, size_t pitch, size_t frame_stride, int device,

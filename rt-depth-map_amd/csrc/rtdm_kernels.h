@@ -109,6 +109,14 @@ void launch_rectify_gray(RectifySrc L, RectifySrc R, const int16_t* map1L, const
 void launch_rectify_rgb(RectifySrc S, const int16_t* map1, const uint16_t* map2, int sW, int sH, int rw, int rh, Plane8W out,
                         int n, hipStream_t stream);
 
+// Object detection that produces the matcher's ROI (estimator.cpp:40-53).  rgb: H x W x 3, R first.
+void launch_hsv_inrange(const uint8_t* rgb, size_t pitch, int W, int H, const int lo[3], const int hi[3], uint8_t* mask,
+                        size_t mpitch, hipStream_t stream);
+size_t cc_scratch_bytes(int W, int H, int max_records);
+// records: (first pixel index, x, y, w, h, external) per 8-connected foreground component, in no particular order
+void launch_cc_boxes(const uint8_t* mask, size_t mpitch, int W, int H, int zero_border, void* scratch, int max_records,
+                     int** d_count, int** d_records, hipStream_t stream);
+
 // Synthetic stream generator (bit-identical to synth.py).
 void launch_synth(uint64_t seed, int first_frame, int n, int W, int H, int D, Plane8W L, Plane8W R,
                   void* param_scratch, hipStream_t stream);

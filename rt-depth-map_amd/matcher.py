@@ -275,6 +275,66 @@ class HIPRectifier:
                                                    d_disp.data_ptr(), stream), "rtdm_bm_compute_rgb_device")
 
 
+HSV_LOW, HSV_HIGH = (0, 150, 0), (9, 255, 255)          # the reference's red filter, estimator.cpp:110-115
+
+
+def _hsv_range(low, high):
+    return B.HsvRange((C.c_int * 3)(*[int(v) for v in low]), (C.c_int * 3)(*[int(v) for v in high]))
+
+
+class HIPObjectDetector:
+    """estimator.cpp:40-53 on the device: HSV threshold -> 10x10-ellipse open+close -> external components -> boxes."""
+
+    def __init__(self, width, height, device=0):
+        self.width, self.height = width, height
+        self._h = C.c_void_p()
+        B.check(B.lib().rtdm_objects_create(width, height, device, C.byref(self._h)), "rtdm_objects_create")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            try:
+                B.lib().rtdm_objects_destroy(self._h)
+            except TypeError:
+                pass
+            self._h = None
+
+    __del__ = close
+
+    def detect(self, rgb, low=HSV_LOW, high=HSV_HIGH, min_area=100, zero_border=True, max_boxes=256):
+        """rgb: HxWx3 uint8 (R first) -> (boxes [(x,y,w,h)], roi (x,y,w,h), mask HxW uint8 = filter_out)."""
+        assert rgb.dtype == np.uint8 and rgb.shape == (self.height, self.width, 3) and rgb.strides[1] == 3 and rgb.strides[2] == 1
+        boxes = (B.Region * max_boxes)(); n = C.c_int(); roi = B.Region()
+        mask = np.empty((self.height, self.width), np.uint8)
+        rng = _hsv_range(low, high)
+        B.check(B.lib().rtdm_objects_detect(self._h, rgb.ctypes.data, rgb.strides[0], C.byref(rng), min_area, int(zero_border),
+                                            mask.ctypes.data, self.width, boxes, max_boxes, C.byref(n), C.byref(roi)),
+                "rtdm_objects_detect")
+        out = [(b.x, b.y, b.width, b.height) for b in boxes[:min(n.value, max_boxes)]]
+        return out, (roi.x, roi.y, roi.width, roi.height), mask
+
+
+def estimate_frame(matcher, rectifier, detector, rgb_left, rgb_right, Q, low=HSV_LOW, high=HSV_HIGH, min_area=100,
+                   zero_border=True, calibration_unit=25.0, max_boxes=64, want_disp=False):
+    """One iteration of Estimator::run (estimator.cpp:29-77) without capture/decode/drawing:
+    -> (boxes, mean_cm, counts[, disp])."""
+    rectifier._check_rgb(rgb_left); rectifier._check_rgb(rgb_right)
+    rw, rh = rectifier.roi[2], rectifier.roi[3]
+    boxes = (B.Region * max_boxes)(); n = C.c_int()
+    mean = np.zeros(max_boxes, np.float64); cnt = np.zeros(max_boxes, np.int32)
+    q = np.ascontiguousarray(Q, np.float64).reshape(16)
+    disp = np.empty((rh, rw), np.int16) if want_disp else None
+    rng = _hsv_range(low, high)
+    B.check(B.lib().rtdm_estimate_frame(matcher._h, rectifier._h, detector._h, rgb_left.ctypes.data, rgb_left.strides[0],
+                                        rgb_right.ctypes.data, rgb_right.strides[0], q.ctypes.data_as(C.POINTER(C.c_double)),
+                                        C.byref(rng), min_area, int(zero_border), calibration_unit, boxes,
+                                        mean.ctypes.data_as(C.POINTER(C.c_double)), cnt.ctypes.data_as(C.POINTER(C.c_int)),
+                                        max_boxes, C.byref(n), disp.ctypes.data if want_disp else None, rw * 2),
+            "rtdm_estimate_frame")
+    k = min(n.value, max_boxes)
+    out = [(b.x, b.y, b.width, b.height) for b in boxes[:k]]
+    return (out, mean[:k], cnt[:k], disp) if want_disp else (out, mean[:k], cnt[:k])
+
+
 def depth_stats_device(d_disp, Q, d_mask, regions, calibration_unit=25.0, device=0, stream=None):
     """torch CUDA tensors: int16 [H,W] x16 disparity, uint8 [H,W] mask -> (mean_cm[n], counts[n]); synchronous."""
     H, W = d_disp.shape

@@ -390,3 +390,55 @@ def init_undistort_rectify_map(M, D, R, P, W, H):
     map1 = np.stack([iu >> 5, iv >> 5], -1).astype(np.int16)
     map2 = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
     return map1, map2
+
+
+# ---- object detection -> ROI (independent of oracle/objects_oracle.c) -----------------------------------------
+def rgb2hsv(rgb):
+    """Per-pixel Python ints, straight from the published fixed-point formulas (hue in [0,180))."""
+    sdiv = [0] + [int(round((255 << 12) / (1.0 * i))) for i in range(1, 256)]
+    hdiv = [0] + [int(round((180 << 12) / (6.0 * i))) for i in range(1, 256)]
+    H, W, _ = rgb.shape
+    out = np.zeros_like(rgb)
+    for y in range(H):
+        for x in range(W):
+            r, g, b = (int(v) for v in rgb[y, x])
+            v, vmin = max(r, g, b), min(r, g, b)
+            diff = v - vmin
+            s = (diff * sdiv[v] + 2048) >> 12
+            if v == r:
+                h = g - b
+            elif v == g:
+                h = b - r + 2 * diff
+            else:
+                h = r - g + 4 * diff
+            h = (h * hdiv[diff] + 2048) >> 12
+            if h < 0:
+                h += 180
+            out[y, x] = (min(max(h, 0), 255), s, v)
+    return out
+
+
+def external_boxes(mask, min_area=100, zero_border=True):
+    """scipy.ndimage labelling; a component is external iff one of its pixels is 4-adjacent to the background that
+    reaches the frame (or lies on the frame itself)."""
+    from scipy import ndimage as ndi
+    m = mask != 0
+    if zero_border:
+        m = m.copy(); m[0, :] = m[-1, :] = False; m[:, 0] = m[:, -1] = False
+    H, W = m.shape
+    pad = np.zeros((H + 2, W + 2), bool); pad[1:-1, 1:-1] = m
+    bg, _ = ndi.label(~pad)                                   # 4-connected by default
+    outer = bg == bg[0, 0]
+    near_outer = ndi.binary_dilation(outer, structure=ndi.generate_binary_structure(2, 1))[1:-1, 1:-1]
+    fg, n = ndi.label(m, structure=np.ones((3, 3), bool))      # 8-connected
+    found = []
+    for i, sl in enumerate(ndi.find_objects(fg), 1):
+        comp = fg[sl] == i
+        if not (comp & near_outer[sl]).any():
+            continue
+        ys, xs = sl
+        first = np.flatnonzero(fg.ravel() == i)[0]
+        box = (xs.start, ys.start, xs.stop - xs.start, ys.stop - ys.start)
+        if box[2] * box[3] >= min_area:
+            found.append((first, box))
+    return [b for _, b in sorted(found, reverse=True)]

@@ -37,3 +37,34 @@ def rgb_pair(synth, seed, W, H):
     left = np.ascontiguousarray(np.stack([a, c, ((a.astype(np.int32) + d) // 2).astype(np.uint8)], -1))
     right = np.ascontiguousarray(np.stack([b, d, ((b.astype(np.int32) + c) // 2).astype(np.uint8)], -1))
     return left, right
+
+
+def red_scene(synth, seed, W, H, D=32, nblobs=6):
+    """Sensor RGB frames for the whole per-frame chain: a synthetic stereo pair as the gray texture, with saturated red
+    objects (hue 0, S > 150: what estimator.cpp:110-115 filters for) painted over it -- ellipses, one ring with a
+    nested blob, one object touching the frame edge, a few specks that the 10x10 opening must erase."""
+    L, R = synth.make_pair(synth.STREAM_SEED + 7000 + seed, W, H, D)
+    rng = np.random.default_rng(900 + seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    m = np.zeros((H, W), bool)
+    for _ in range(nblobs):
+        cx, cy = rng.integers(W // 5, 4 * W // 5), rng.integers(H // 4, 3 * H // 4)
+        a, b = rng.integers(W // 30 + 6, W // 10 + 8), rng.integers(H // 30 + 6, H // 8 + 8)
+        m |= ((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2 <= 1
+    cx, cy, r = W // 2, H // 2, min(W, H) // 6
+    d2 = (xx - cx) ** 2 + (yy - cy) ** 2
+    m &= ~(d2 <= (r + 14) ** 2)
+    m |= (d2 <= (r + 12) ** 2) & (d2 >= (r - 2) ** 2)            # ring ...
+    m |= d2 <= (r // 3) ** 2                                      # ... with a nested blob
+    m[H // 3:H // 3 + 40, :W // 4] |= xx[H // 3:H // 3 + 40, :W // 4] < W // 5    # reaches the left frame edge
+    for _ in range(30):
+        x, y = rng.integers(0, W - 4), rng.integers(0, H - 4)
+        m[y:y + 3, x:x + 3] = True                                # specks
+    out = []
+    for g in (L, R):
+        g16 = g.astype(np.int32)
+        rgb = np.stack([g, g, g], -1)
+        red = np.stack([150 + g16 // 3, g16 // 6, g16 // 6], -1).astype(np.uint8)
+        rgb[m] = red[m]
+        out.append(np.ascontiguousarray(rgb))
+    return out[0], out[1]
