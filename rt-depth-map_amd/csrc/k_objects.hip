@@ -46,13 +46,31 @@ __device__ __forceinline__ bool cc_fg(const uint8_t* mask, size_t mpitch, int W,
     return mask[(size_t)y * mpitch + x] != 0;
 }
 
-__global__ __launch_bounds__(256) void k_cc_init(int32_t* label, int4* box, int W, int N, int* count)
+struct OpMax {
+    static __device__ int id() { return 0; }
+    static __device__ int f(int a, int b) { return max(a, b); }
+};
+
+// One workgroup per row: every pixel's parent becomes the first pixel of its horizontal run of same-kind pixels
+// (max-scan of "run starts here" flags), so no union is ever needed along a row.
+__global__ __launch_bounds__(256) void k_cc_rows(const uint8_t* mask, size_t mpitch, int32_t* label, int4* box, int W, int H,
+                                                 int zero_border, int* count)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p > N) return;
-    label[p] = p;
-    if (p < N) { const int y = p / W, x = p - y * W; box[p] = make_int4(x, y, x, y); }
-    if (p == 0) *count = 0;
+    extern __shared__ int sc[];
+    __shared__ int wsum[4];
+    const int y = blockIdx.x;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const bool v = cc_fg(mask, mpitch, W, H, x, y, zero_border);
+        const bool start = x == 0 || cc_fg(mask, mpitch, W, H, x - 1, y, zero_border) != v;
+        sc[x] = start ? x + 1 : 0;
+    }
+    __syncthreads();
+    row_scan<OpMax>(sc, W, wsum);
+    for (int x = threadIdx.x; x < W; x += 256) {
+        label[y * W + x] = y * W + sc[x] - 1;
+        box[y * W + x] = make_int4(x, y, x, y);
+    }
+    if (y == 0 && threadIdx.x == 0) { label[W * H] = W * H; *count = 0; }
 }
 
 __global__ __launch_bounds__(256) void k_cc_merge(const uint8_t* mask, size_t mpitch, int32_t* label, int W, int H, int zero_border)
@@ -61,32 +79,38 @@ __global__ __launch_bounds__(256) void k_cc_merge(const uint8_t* mask, size_t mp
     if (p >= W * H) return;
     const int y = p / W, x = p - y * W;
     const bool v = cc_fg(mask, mpitch, W, H, x, y, zero_border);
+    const bool hasL = x > 0, hasU = y > 0;
+    const bool l = hasL && cc_fg(mask, mpitch, W, H, x - 1, y, zero_border) == v;            // left neighbour of my kind
+    const bool u = hasU && cc_fg(mask, mpitch, W, H, x, y - 1, zero_border) == v;            // upper neighbour of my kind
+    const bool ul = hasL && hasU && cc_fg(mask, mpitch, W, H, x - 1, y - 1, zero_border) == v;
+    // a vertical contact needs one union per segment: if my left neighbour and the pixel above it are of my kind too,
+    // they made the link for both runs (rows are already joined by k_cc_rows)
+    if (u && !(l && ul)) uf_union(label, p, p - W);
     if (v) {
-        if (x > 0 && cc_fg(mask, mpitch, W, H, x - 1, y, zero_border)) uf_union(label, p, p - 1);
-        if (y > 0) {
-            const bool up = cc_fg(mask, mpitch, W, H, x, y - 1, zero_border);
-            if (up) uf_union(label, p, p - W);
-            // the diagonals are implied by `up` together with the row-wise unions of the row above
-            if (!up && x > 0 && cc_fg(mask, mpitch, W, H, x - 1, y - 1, zero_border)) uf_union(label, p, p - W - 1);
-            if (!up && x + 1 < W && cc_fg(mask, mpitch, W, H, x + 1, y - 1, zero_border)) uf_union(label, p, p - W + 1);
-        }
-    } else {
-        if (x > 0 && !cc_fg(mask, mpitch, W, H, x - 1, y, zero_border)) uf_union(label, p, p - 1);
-        if (y > 0 && !cc_fg(mask, mpitch, W, H, x, y - 1, zero_border)) uf_union(label, p, p - W);
-        if (x == 0 || y == 0 || x == W - 1 || y == H - 1) uf_union(label, p, W * H);
+        // foreground is 8-connected; the diagonals matter only when the pixel above is background
+        if (!u && ul) uf_union(label, p, p - W - 1);
+        if (!u && hasU && x + 1 < W && cc_fg(mask, mpitch, W, H, x + 1, y - 1, zero_border)) uf_union(label, p, p - W + 1);
+    } else if ((x == 0 || y == 0 || x == W - 1 || y == H - 1) && !(l && (y == 0 || y == H - 1)) && !(u && (x == 0 || x == W - 1))) {
+        uf_union(label, p, W * H);                       // background on the image border hangs on the frame node (once per border run)
     }
 }
 
+// Boxes from the horizontal runs only: a run's first pixel reports (min x, min y, max y), its last pixel (max x).
+// A blob of 100k pixels would otherwise serialise 400k atomics on the four words of its root.
 __global__ __launch_bounds__(256) void k_cc_bbox(const uint8_t* mask, size_t mpitch, int32_t* label, int4* box, int W, int H, int zero_border)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= W * H) return;
     const int y = p / W, x = p - y * W;
     if (!cc_fg(mask, mpitch, W, H, x, y, zero_border)) return;
+    const bool first = x == 0 || !cc_fg(mask, mpitch, W, H, x - 1, y, zero_border);
+    const bool last = x == W - 1 || !cc_fg(mask, mpitch, W, H, x + 1, y, zero_border);
+    if (!first && !last) return;
     const int r = uf_find(label, p);
     if (r == p) return;                                  // the root's own coordinates are its initial box
     int* b = (int*)&box[r];
-    atomicMin(b + 0, x); atomicMin(b + 1, y); atomicMax(b + 2, x); atomicMax(b + 3, y);
+    if (first) { atomicMin(b + 0, x); atomicMin(b + 1, y); atomicMax(b + 3, y); }
+    if (last) atomicMax(b + 2, x);
 }
 
 // one record per foreground root: first pixel, box, external flag
@@ -135,7 +159,7 @@ void launch_cc_boxes(const uint8_t* mask, size_t mpitch, int W, int H, int zero_
     int* records = (int*)s;                       s += (size_t)max_records * 24;
     int* count = (int*)s;
     const dim3 grid((N + 1 + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_cc_init, grid, block, 0, stream, label, box, W, N, count);
+    hipLaunchKernelGGL(k_cc_rows, dim3(H), block, (size_t)W * sizeof(int), stream, mask, mpitch, label, box, W, H, zero_border, count);
     hipLaunchKernelGGL(k_cc_merge, grid, block, 0, stream, mask, mpitch, label, W, H, zero_border);
     hipLaunchKernelGGL(k_cc_bbox, grid, block, 0, stream, mask, mpitch, label, box, W, H, zero_border);
     hipLaunchKernelGGL(k_cc_collect, grid, block, 0, stream, mask, mpitch, label, box, W, H, zero_border, count, records, max_records);

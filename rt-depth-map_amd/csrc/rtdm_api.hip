@@ -860,7 +860,7 @@ int rtdm_rectify_create(const int16_t* map1_left, const uint16_t* map2_left, con
         if (e == hipSuccess) e = hipMalloc((void**)&rc->dGray[k], rc->gpitch * roi_height * (size_t)max_batch);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&rc->dOut, npx * 3);
-    if (e == hipSuccess) e = hipHostMalloc((void**)&rc->hStage, 2 * fbytes + npx * 3, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&rc->hStage, 2 * fbytes + npx * 3 + 128 * (size_t)roi_height, hipHostMallocDefault);
     if (e == hipSuccess) {
         // crop the maps on the host (through the pinned area), one linear copy each
         for (int k = 0; k < 2 && e == hipSuccess; ++k) {
@@ -922,9 +922,16 @@ int rtdm_rectify_gray(rtdm_rectify* rc, const uint8_t* rgb_left, size_t left_pit
     const size_t gframe = rc->gpitch * rc->rh;
     rectify_gray_launch(rc, rc->dRgb[0], rc->dRgb[1], 1, Plane8W{rc->dGray[0], rc->gpitch, gframe}, Plane8W{rc->dGray[1], rc->gpitch, gframe}, s);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpy2DAsync(left_rect, left_rect_pitch, rc->dGray[0], rc->gpitch, rc->rw, rc->rh, hipMemcpyDeviceToHost, s));
-    HIPC(hipMemcpy2DAsync(right_rect, right_rect_pitch, rc->dGray[1], rc->gpitch, rc->rw, rc->rh, hipMemcpyDeviceToHost, s));
+    // back through the page-locked area (2-D copies into pageable memory take the slow path)
+    uint8_t* hl = rc->hStage + 2 * (size_t)rc->W * rc->H * 3;
+    uint8_t* hr = hl + gframe;
+    HIPC(hipMemcpyAsync(hl, rc->dGray[0], gframe, hipMemcpyDeviceToHost, s));
+    HIPC(hipMemcpyAsync(hr, rc->dGray[1], gframe, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    for (int y = 0; y < rc->rh; ++y) {
+        memcpy(left_rect + (size_t)y * left_rect_pitch, hl + (size_t)y * rc->gpitch, (size_t)rc->rw);
+        memcpy(right_rect + (size_t)y * right_rect_pitch, hr + (size_t)y * rc->gpitch, (size_t)rc->rw);
+    }
     return RTDM_OK;
 }
 
@@ -940,8 +947,10 @@ int rtdm_rectify_rgb(rtdm_rectify* rc, int which, const uint8_t* rgb, size_t pit
     launch_rectify_rgb(RectifySrc{rc->dRgb[0], row, fbytes}, rc->dMap1[which], rc->dMap2[which], rc->W, rc->H, rc->rw, rc->rh,
                        Plane8W{rc->dOut, (size_t)rc->rw * 3, (size_t)rc->rw * 3 * rc->rh}, 1, s);
     HIPC(hipGetLastError());
-    HIPC(hipMemcpy2DAsync(out, out_pitch, rc->dOut, (size_t)rc->rw * 3, (size_t)rc->rw * 3, rc->rh, hipMemcpyDeviceToHost, s));
+    uint8_t* ho = rc->hStage + 2 * fbytes;
+    HIPC(hipMemcpyAsync(ho, rc->dOut, (size_t)rc->rw * 3 * rc->rh, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
+    for (int y = 0; y < rc->rh; ++y) memcpy(out + (size_t)y * out_pitch, ho + (size_t)y * rc->rw * 3, (size_t)rc->rw * 3);
     return RTDM_OK;
 }
 
@@ -1040,6 +1049,7 @@ int rtdm_objects_create(int width, int height, int device, rtdm_objects** out)
     if (!out) return RTDM_ERR_NULL;
     *out = nullptr;
     if (width <= 0 || height <= 0 || width > 32767 || height > 32767 || (long)width * height >= (1L << 30)) return RTDM_ERR_BAD_SIZE;
+    if (width > 8192) return RTDM_ERR_UNSUPPORTED;      // the component labelling keeps one row of ints in LDS
     int st = use_device(device);
     if (st) return st;
     rtdm_objects* ob = new (std::nothrow) rtdm_objects();
@@ -1118,9 +1128,10 @@ int rtdm_objects_detect(rtdm_objects* ob, const uint8_t* rgb, size_t pitch, cons
     HIPC(hipMemcpyAsync(ob->dRgb, h, row * ob->H, hipMemcpyHostToDevice, s));
     int st = objects_run(ob, range, min_area, zero_border, boxes, max_boxes, nboxes, roi, s);
     if (st) return st;
-    if (mask_out) {
-        HIPC(hipMemcpy2DAsync(mask_out, mask_pitch, ob->dMaskOut, (size_t)ob->W, (size_t)ob->W, ob->H, hipMemcpyDeviceToHost, s));
+    if (mask_out) {                                     // through the page-locked area (the upload is long done)
+        HIPC(hipMemcpyAsync(h, ob->dMaskOut, (size_t)ob->W * ob->H, hipMemcpyDeviceToHost, s));
         HIPC(hipStreamSynchronize(s));
+        for (int y = 0; y < ob->H; ++y) memcpy(mask_out + (size_t)y * mask_pitch, h + (size_t)y * ob->W, (size_t)ob->W);
     }
     return RTDM_OK;
 }

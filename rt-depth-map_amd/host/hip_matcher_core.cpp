@@ -84,6 +84,41 @@ int HIPRectifierCore::compute(HIPMatcherCore& matcher, const uint8_t* rgbLeft, s
     return status_ = rtdm_bm_compute_rgb(matcher.handle(), rc_, rgbLeft, leftStep, rgbRight, rightStep, out, outStep);
 }
 
+HIPObjectsCore::HIPObjectsCore(int cols, int rows, int device)
+{
+    setRange(0, 150, 0, 9, 255, 255);                                  // estimator.cpp:110-115
+    status_ = rtdm_objects_create(cols, rows, device, &ob_);
+    if (status_ != RTDM_OK) std::fprintf(stderr, "HIPObjects: %s\n", rtdm_strerror(status_));
+}
+HIPObjectsCore::~HIPObjectsCore() { rtdm_objects_destroy(ob_); }
+void HIPObjectsCore::setRange(int lowH, int lowS, int lowV, int highH, int highS, int highV)
+{
+    range_.low[0] = lowH; range_.low[1] = lowS; range_.low[2] = lowV;
+    range_.high[0] = highH; range_.high[1] = highS; range_.high[2] = highV;
+}
+int HIPObjectsCore::detect(const uint8_t* rgb, size_t step, int minObjSize, bool zeroBorder, uint8_t* maskOut, size_t maskStep,
+                           Rect* boxes, int maxBoxes, Rect* matchingRoi)
+{
+    if (!ob_) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    static_assert(sizeof(Rect) == sizeof(rtdm_region), "Rect and rtdm_region share their layout");
+    int n = 0;
+    status_ = rtdm_objects_detect(ob_, rgb, step, &range_, minObjSize, zeroBorder ? 1 : 0, maskOut, maskStep,
+                                  reinterpret_cast<rtdm_region*>(boxes), maxBoxes, &n, reinterpret_cast<rtdm_region*>(matchingRoi));
+    return status_ == RTDM_OK ? n : status_;
+}
+int HIPObjectsCore::estimateFrame(HIPMatcherCore& matcher, HIPRectifierCore& rectifier, const uint8_t* rgbLeft, size_t leftStep,
+                                  const uint8_t* rgbRight, size_t rightStep, const double* Q, int minObjSize, bool zeroBorder,
+                                  double calibrationUnit, Rect* boxes, double* meanCm, int* counts, int maxBoxes,
+                                  int16_t* disp, size_t dispStep)
+{
+    if (!ob_ || !matcher.handle() || !rectifier.handle()) return status_ != RTDM_OK ? status_ : RTDM_ERR_NO_DEVICE;
+    int n = 0;
+    status_ = rtdm_estimate_frame(matcher.handle(), rectifier.handle(), ob_, rgbLeft, leftStep, rgbRight, rightStep, Q, &range_,
+                                  minObjSize, zeroBorder ? 1 : 0, calibrationUnit, reinterpret_cast<rtdm_region*>(boxes), meanCm,
+                                  counts, maxBoxes, &n, disp, dispStep);
+    return status_ == RTDM_OK ? n : status_;
+}
+
 HIPSGMCore::HIPSGMCore(int blockSize, int minDisparity, int numOfDisparities, int uniquenessRatio, int speckleWindowSize,
                        int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device)
 {

@@ -98,9 +98,38 @@ public:
     int compute(HIPMatcherCore& matcher, const uint8_t* rgbLeft, size_t leftStep, const uint8_t* rgbRight, size_t rightStep,
                 int16_t* out, size_t outStep);
     int status() const { return status_; }
+    rtdm_rectify* handle() { return rc_; }
 
 private:
     rtdm_rectify* rc_ = nullptr;
+    int status_ = RTDM_OK;
+};
+
+// The caller's lines between rectification and the matcher (/root/reference/estimator.cpp:40-53): HSV threshold of the
+// rectified colour crop, the morphological filter, findContours(RETR_EXTERNAL) + boundingRect + the minimum-size filter
+// (fill_bounding_rects_of_contours, :167-174) and the union box (find_relevant_matching_region, :176-204).
+// estimateFrame() is one whole iteration of Estimator::run without capture, decode and drawing (:29-77).
+class HIPObjectsCore {
+public:
+    HIPObjectsCore(int cols, int rows, int device = 0);       // size of the crop (roif)
+    ~HIPObjectsCore();
+    HIPObjectsCore(const HIPObjectsCore&) = delete;
+    HIPObjectsCore& operator=(const HIPObjectsCore&) = delete;
+    // thresholds as the Estimator's members iLowH ... iHighV (estimator.cpp:110-115)
+    void setRange(int lowH, int lowS, int lowV, int highH, int highS, int highV);
+    // rgb: rows x cols x 3 (R first); maskOut (filter_out) may be null.  Returns the number of boxes (>= 0; only
+    // maxBoxes are stored) or a negative status.  zeroBorder: true = findContours of OpenCV <= 3.1.
+    int detect(const uint8_t* rgb, size_t step, int minObjSize, bool zeroBorder, uint8_t* maskOut, size_t maskStep,
+               Rect* boxes, int maxBoxes, Rect* matchingRoi);
+    int estimateFrame(HIPMatcherCore& matcher, HIPRectifierCore& rectifier, const uint8_t* rgbLeft, size_t leftStep,
+                      const uint8_t* rgbRight, size_t rightStep, const double* Q, int minObjSize, bool zeroBorder,
+                      double calibrationUnit, Rect* boxes, double* meanCm, int* counts, int maxBoxes,
+                      int16_t* disp = nullptr, size_t dispStep = 0);
+    int status() const { return status_; }
+
+private:
+    rtdm_objects* ob_ = nullptr;
+    rtdm_hsv_range range_;
     int status_ = RTDM_OK;
 };
 
