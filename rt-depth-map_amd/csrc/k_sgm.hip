@@ -6,8 +6,9 @@
 // and are laid out [frame][y][x - x0][d] with d fastest, so a wavefront's lanes = consecutive
 // disparities = one coalesced line per pixel.
 //
-//   k_sgm_grad   x-Sobel (vertical edge replication) clipped to +-15, + 15           (HBM bound)
-//   k_sgm_pix    Birchfield-Tomasi pixel cost, gradient + (intensity >> 2) -> u8      (lanes = d)
+//   k_sgm_bounds x-Sobel (vertical edge replication) clipped to +-15, + 15, and the BT bounds of it and of the
+//                intensity, per pixel                                                  (HBM bound)
+//   k_sgm_pix    Birchfield-Tomasi pixel cost, gradient + (intensity >> 2) -> u8      (thread = 4 d)
 //   k_sgm_box    blockSize x blockSize sum with clamped coordinates -> C (u16)
 //   k_sgm_path   one workgroup per path line, one thread per disparity: L_r recurrence with the
 //                neighbours and the line minimum exchanged through double-buffered LDS (one barrier
@@ -17,11 +18,28 @@
 #include "rtdm_kernels.h"
 #include "rtdm_device.h"
 
+#include <cstdlib>
+
 namespace rtdm {
 
 static constexpr int FTZ = 15;
 
-__global__ __launch_bounds__(256) void k_sgm_grad(Plane8 L, Plane8 R, uint8_t* gl, uint8_t* gr, int W, int H, int n)
+// Per pixel and image, once: the Birchfield-Tomasi bounds (value, min and max against the half-way points to the two
+// neighbours) of the clipped x-gradient and of the raw intensity, packed as two uchar4 -- the pixel-cost kernel then
+// needs one 8-byte load per (pixel, image) instead of six byte loads per (pixel, disparity, image).
+__device__ __forceinline__ int sgm_grad(const uint8_t* r0, const uint8_t* r1, const uint8_t* r2, int x, int W)
+{
+    if (x <= 0 || x >= W - 1) return FTZ;
+    const int g = ((int)r1[x + 1] - (int)r1[x - 1]) * 2 + ((int)r0[x + 1] - (int)r0[x - 1]) + ((int)r2[x + 1] - (int)r2[x - 1]);
+    return min(max(g, -FTZ), FTZ) + FTZ;
+}
+__device__ __forceinline__ uint32_t bt_pack(int v, int m, int p, bool has_m, bool has_p)
+{
+    const int l = has_m ? (v + m) / 2 : v, r = has_p ? (v + p) / 2 : v;
+    return (uint32_t)v | ((uint32_t)min(min(l, r), v) << 8) | ((uint32_t)max(max(l, r), v) << 16);
+}
+
+__global__ __launch_bounds__(256) void k_sgm_bounds(Plane8 L, Plane8 R, uint2* bl, uint2* br, int W, int H, int n)
 {
     const int x = blockIdx.x * 256 + threadIdx.x;
     if (x >= W) return;
@@ -31,86 +49,90 @@ __global__ __launch_bounds__(256) void k_sgm_grad(Plane8 L, Plane8 R, uint8_t* g
     if (right) f -= n;
     const Plane8 S = right ? R : L;
     const uint8_t* img = S.base + (size_t)f * S.frame;
-    int v = FTZ;
-    if (x > 0 && x < W - 1) {
-        const uint8_t* r1 = img + (size_t)y * S.pitch;
-        const uint8_t* r0 = img + (size_t)(y > 0 ? y - 1 : y) * S.pitch;
-        const uint8_t* r2 = img + (size_t)(y < H - 1 ? y + 1 : y) * S.pitch;
-        const int g = ((int)r1[x + 1] - (int)r1[x - 1]) * 2 + ((int)r0[x + 1] - (int)r0[x - 1]) + ((int)r2[x + 1] - (int)r2[x - 1]);
-        v = min(max(g, -FTZ), FTZ) + FTZ;
-    }
-    (right ? gr : gl)[((size_t)f * H + y) * W + x] = (uint8_t)v;
+    const uint8_t* r1 = img + (size_t)y * S.pitch;
+    const uint8_t* r0 = img + (size_t)(y > 0 ? y - 1 : y) * S.pitch;
+    const uint8_t* r2 = img + (size_t)(y < H - 1 ? y + 1 : y) * S.pitch;
+    const bool hm = x > 0, hp = x < W - 1;
+    const uint32_t gb = bt_pack(sgm_grad(r0, r1, r2, x, W), hm ? sgm_grad(r0, r1, r2, x - 1, W) : 0,
+                                hp ? sgm_grad(r0, r1, r2, x + 1, W) : 0, hm, hp);
+    const uint32_t rb = bt_pack(r1[x], hm ? r1[x - 1] : 0, hp ? r1[x + 1] : 0, hm, hp);
+    (right ? br : bl)[((size_t)f * H + y) * W + x] = make_uint2(gb, rb);
 }
 
-__device__ __forceinline__ void bt_bounds(const uint8_t* row, int x, int W, int& v, int& lo, int& hi)
+__device__ __forceinline__ int bt_cost(uint32_t a, uint32_t b)
 {
-    v = row[x];
-    const int l = x > 0 ? (v + (int)row[x - 1]) / 2 : v;
-    const int r = x < W - 1 ? (v + (int)row[x + 1]) / 2 : v;
-    lo = min(min(l, r), v); hi = max(max(l, r), v);
+    const int u = a & 0xff, u0 = (a >> 8) & 0xff, u1 = (a >> 16) & 0xff;
+    const int v = b & 0xff, v0 = (b >> 8) & 0xff, v1 = (b >> 16) & 0xff;
+    const int c0 = max(0, max(u - v1, v0 - u));
+    const int c1 = max(0, max(v - u1, u0 - v));
+    return min(c0, c1);
 }
 
-// pixel cost, u8: one thread per (x, d); d fastest
-__global__ __launch_bounds__(256) void k_sgm_pix(Plane8 L, Plane8 R, const uint8_t* gl, const uint8_t* gr, uint8_t* pix,
-                                                 SGMGeom g)
+// pixel cost, u8: one thread per (x, four consecutive d); d fastest
+__global__ __launch_bounds__(256) void k_sgm_pix(const uint2* bl, const uint2* br, uint8_t* pix, SGMGeom g)
 {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D
-    if (idx >= (size_t)g.W1 * g.D) return;
-    const int d = (int)(idx % g.D), xi = (int)(idx / g.D);
+    const int dq = g.D >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D/4
+    if (idx >= (size_t)g.W1 * dq) return;
+    const int d = (int)(idx % dq) * 4, xi = (int)(idx / dq);
     const int y = blockIdx.y, f = blockIdx.z;
-    const int x = g.x0 + xi, xr = x - (d + g.minD);
-    const uint8_t* lrow = L.base + (size_t)f * L.frame + (size_t)y * L.pitch;
-    const uint8_t* rrow = R.base + (size_t)f * R.frame + (size_t)y * R.pitch;
-    const uint8_t* glrow = gl + ((size_t)f * g.H + y) * g.W;
-    const uint8_t* grrow = gr + ((size_t)f * g.H + y) * g.W;
-    int c = 0;
+    const int x = g.x0 + xi, xr = x - (d + g.minD);                     // element j pairs x with xr - j
+    const size_t row = ((size_t)f * g.H + y) * g.W;
+    const uint2 a = bl[row + x];
+    uint32_t out = 0;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const uint8_t* a = pass ? lrow : glrow;
-        const uint8_t* b = pass ? rrow : grrow;
-        int u, u0, u1, v, v0, v1;
-        bt_bounds(a, x, g.W, u, u0, u1);
-        bt_bounds(b, xr, g.W, v, v0, v1);
-        const int c0 = max(0, max(u - v1, v0 - u));
-        const int c1 = max(0, max(v - u1, u0 - v));
-        c += min(c0, c1) >> (pass ? 2 : 0);
+    for (int j = 0; j < 4; ++j) {
+        const uint2 b = br[row + xr - j];
+        const int c = bt_cost(a.x, b.x) + (bt_cost(a.y, b.y) >> 2);
+        out |= (uint32_t)c << (8 * j);
     }
-    pix[(((size_t)f * g.H + y) * g.W1 + xi) * g.D + d] = (uint8_t)c;
+    *(uint32_t*)(pix + (((size_t)f * g.H + y) * g.W1 + xi) * g.D + d) = out;
 }
 
-// block cost: thread = (x, d); walks down a strip of rows keeping the last 2R+1 horizontal sums in
+// block cost: thread = (x, four consecutive d); walks down a strip of rows keeping the last 2R+1 horizontal sums in
 // registers, so every pixel-cost element is read (2R+1) times instead of (2R+1)^2 times
 template <int R>
 __global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C, SGMGeom g, int rows_per_strip)
 {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D
-    if (idx >= (size_t)g.W1 * g.D) return;
-    const int d = (int)(idx % g.D), xi = (int)(idx / g.D);
+    const int dq = g.D >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D/4
+    if (idx >= (size_t)g.W1 * dq) return;
+    const int d = (int)(idx % dq) * 4, xi = (int)(idx / dq);
     const int f = blockIdx.z;
     const int y0 = blockIdx.y * rows_per_strip, y1 = min(y0 + rows_per_strip, g.H);
     const uint8_t* base = pix + (size_t)f * g.H * g.W1 * g.D + d;
     int xs[2 * R + 1];
 #pragma unroll
     for (int k = 0; k <= 2 * R; ++k) xs[k] = min(max(xi + k - R, 0), g.W1 - 1) * g.D;
-    const auto hsum = [&](int y) -> int {
+    struct Sum4 { int v[4]; };
+    const auto hsum = [&](int y) -> Sum4 {
         const uint8_t* row = base + (size_t)min(max(y, 0), g.H - 1) * g.W1 * g.D;
-        int s = 0;
+        Sum4 s = {{0, 0, 0, 0}};
 #pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) s += row[xs[k]];
+        for (int k = 0; k <= 2 * R; ++k) {
+            const uint32_t w = *(const uint32_t*)(row + xs[k]);
+            s.v[0] += w & 0xff; s.v[1] += (w >> 8) & 0xff; s.v[2] += (w >> 16) & 0xff; s.v[3] += w >> 24;
+        }
         return s;
     };
-    int ring[2 * R + 1];
-    int sum = 0;
+    Sum4 ring[2 * R + 1];
+    int sum[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int k = 0; k <= 2 * R; ++k) { ring[k] = hsum(y0 - R + k); sum += ring[k]; }
+    for (int k = 0; k <= 2 * R; ++k) {
+        ring[k] = hsum(y0 - R + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[j] += ring[k].v[j];
+    }
     uint16_t* out = C + (((size_t)f * g.H) * g.W1 + xi) * g.D + d;
     for (int y = y0; y < y1; y += 2 * R + 1) {
 #pragma unroll
         for (int k = 0; k <= 2 * R; ++k) {
             if (y + k < y1) {
-                out[(size_t)(y + k) * g.W1 * g.D] = (uint16_t)sum;
-                const int h = hsum(y + k + R + 1);
-                sum += h - ring[k];
+                *(uint2*)(out + (size_t)(y + k) * g.W1 * g.D) =
+                    make_uint2((uint32_t)sum[0] | ((uint32_t)sum[1] << 16), (uint32_t)sum[2] | ((uint32_t)sum[3] << 16));
+                const Sum4 h = hsum(y + k + R + 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { sum[j] += h.v[j] - ring[k].v[j]; }
                 ring[k] = h;
             }
         }
@@ -174,6 +196,104 @@ __global__ __launch_bounds__(256) void k_sgm_path(const uint16_t* C, uint16_t* S
         if ((threadIdx.x & 63) == 0) wmin[step & 1][wv] = m;
         __syncthreads();
         x = nx; y = ny; ++step;
+    }
+}
+
+// Wave-per-line form of k_sgm_path: one WAVE walks one path line, lane l holds the NPL consecutive disparities
+// l*NPL .. l*NPL+NPL-1 (NPL divides D), so the recurrence needs no LDS and no barrier: d-1 / d+1 of the lane's end
+// elements come from the neighbouring lanes by DPP wave shifts, the line minimum by a DPP reduction.  The walk is a
+// serial chain of W1 (or H) steps whose loads would each cost a full memory round trip, so C and S are fetched PF
+// steps ahead through a register ring.  S (+)= L_r, same values as k_sgm_path.
+template <int NPL> struct PackU16 { uint16_t v[NPL]; };
+
+template <int NPL>
+__device__ __forceinline__ PackU16<NPL> ld_pack(const uint16_t* p)
+{
+    PackU16<NPL> r;
+    if constexpr (NPL == 2) { const uint32_t w = *(const uint32_t*)p; r.v[0] = (uint16_t)w; r.v[1] = (uint16_t)(w >> 16); }
+    else if constexpr (NPL == 4) { const uint2 w = *(const uint2*)p; r.v[0] = (uint16_t)w.x; r.v[1] = (uint16_t)(w.x >> 16); r.v[2] = (uint16_t)w.y; r.v[3] = (uint16_t)(w.y >> 16); }
+    else { for (int j = 0; j < NPL; ++j) r.v[j] = p[j]; }
+    return r;
+}
+template <int NPL>
+__device__ __forceinline__ void st_pack(uint16_t* p, const int* l)
+{
+    if constexpr (NPL == 2) { *(uint32_t*)p = (uint32_t)(l[0] & 0xffff) | ((uint32_t)l[1] << 16); }
+    else if constexpr (NPL == 4) { *(uint2*)p = make_uint2((uint32_t)(l[0] & 0xffff) | ((uint32_t)l[1] << 16), (uint32_t)(l[2] & 0xffff) | ((uint32_t)l[3] << 16)); }
+    else { for (int j = 0; j < NPL; ++j) p[j] = (uint16_t)l[j]; }
+}
+
+template <int NPL, int PF>
+__global__ __launch_bounds__(256) void k_sgm_path_w(const uint16_t* C, uint16_t* S, SGMGeom g, int dx, int dy, int P1, int P2,
+                                                    int first_dir, int nlines)
+{
+    const int lane = threadIdx.x & 63;
+    const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= nlines) return;                                   // whole waves only
+    const int D = g.D, W1 = g.W1, H = g.H;
+    int sx, sy;
+    if (dy == 0) { sy = line; sx = dx > 0 ? 0 : W1 - 1; }
+    else if (dx == 0) { sx = line; sy = dy > 0 ? 0 : H - 1; }
+    else if (line < W1) { sx = line; sy = dy > 0 ? 0 : H - 1; }
+    else { const int k = line - W1 + 1; sx = dx > 0 ? 0 : W1 - 1; sy = dy > 0 ? k : H - 1 - k; }
+    const int nx = dx > 0 ? W1 - sx : (dx < 0 ? sx + 1 : 0x7fffffff);
+    const int ny = dy > 0 ? H - sy : (dy < 0 ? sy + 1 : 0x7fffffff);
+    const int nsteps = min(nx, ny);
+    const int d0 = lane * NPL;
+    const bool live = d0 < D;
+    const int BIG = 1 << 28;
+    const long stride = ((long)dy * W1 + dx) * D;
+    const size_t off0 = (size_t)blockIdx.y * H * W1 * D + ((size_t)sy * W1 + sx) * D + (live ? d0 : 0);
+    const uint16_t* cp = C + off0;
+    uint16_t* sp = S + off0;
+    PackU16<NPL> cr[PF], sr[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        if (k < nsteps) {
+            cr[k] = ld_pack<NPL>(cp + (long)k * stride);
+            if (!first_dir) sr[k] = ld_pack<NPL>(sp + (long)k * stride);
+        }
+    }
+    int l[NPL];
+    int mprev = 0;
+    for (int base = 0; base < nsteps; base += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int step = base + k;
+            if (step >= nsteps) break;
+            const PackU16<NPL> c = cr[k], sv = sr[k];
+            if (step + PF < nsteps) {
+                cr[k] = ld_pack<NPL>(cp + (long)(step + PF) * stride);
+                if (!first_dir) sr[k] = ld_pack<NPL>(sp + (long)(step + PF) * stride);
+            }
+            if (step == 0) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) l[j] = live ? (int)c.v[j] : BIG;
+            } else {
+                // neighbours of the lane's end elements: lane-1's last, lane+1's first (BIG outside the wave)
+                const int lo = __builtin_amdgcn_update_dpp(BIG, l[NPL - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+                const int hi = __builtin_amdgcn_update_dpp(BIG, l[0], 0x130, 0xf, 0xf, false);         // wave_shl:1
+                int nl[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) {
+                    const int dn = j ? l[j - 1] : lo, up = j + 1 < NPL ? l[j + 1] : hi;
+                    const int best = min(min(l[j], mprev + P2), min(dn, up) + P1);
+                    nl[j] = live ? (int)c.v[j] + best - mprev : BIG;
+                }
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) l[j] = nl[j];
+            }
+            if (live) {
+                int o[NPL];
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) o[j] = first_dir ? l[j] : (int)sv.v[j] + l[j];
+                st_pack<NPL>(sp + (long)step * stride, o);
+            }
+            int m = l[0];
+#pragma unroll
+            for (int j = 1; j < NPL; ++j) m = min(m, l[j]);
+            mprev = wave_min_i32(m);
+        }
     }
 }
 
@@ -272,9 +392,9 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
                 int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int n, hipStream_t stream)
 {
     dim3 blk(256);
-    hipLaunchKernelGGL(k_sgm_grad, dim3((g.W + 255) / 256, g.H, 2 * n), blk, 0, stream, L, R, b.gl, b.gr, g.W, g.H, n);
-    const unsigned nxd = (unsigned)(((size_t)g.W1 * g.D + 255) / 256);
-    hipLaunchKernelGGL(k_sgm_pix, dim3(nxd, g.H, n), blk, 0, stream, L, R, b.gl, b.gr, b.pix, g);
+    hipLaunchKernelGGL(k_sgm_bounds, dim3((g.W + 255) / 256, g.H, 2 * n), blk, 0, stream, L, R, (uint2*)b.gl, (uint2*)b.gr, g.W, g.H, n);
+    const unsigned nxd = (unsigned)(((size_t)g.W1 * (g.D / 4) + 255) / 256);       // D is a multiple of 16
+    hipLaunchKernelGGL(k_sgm_pix, dim3(nxd, g.H, n), blk, 0, stream, (const uint2*)b.gl, (const uint2*)b.gr, b.pix, g);
     {
         const int rps = 48, strips = (g.H + rps - 1) / rps;
         const dim3 bgrid(nxd, strips, n);
@@ -287,10 +407,26 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     }
     static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1}};
     const int threads = (g.D + 63) & ~63;
+    int npl = (g.D + 63) / 64;                       // disparities per lane of the wave-per-line kernel: must divide D
+    if (g.D % npl) npl = 4;
+    static int wave_paths = -1;
+    if (wave_paths < 0) { const char* e = getenv("RTDM_SGM_WAVE_PATHS"); wave_paths = e ? atoi(e) : 1; }
+    const bool aligned = (((size_t)b.C | (size_t)b.S) & 7) == 0;
     for (int k = 0; k < 8; ++k) {
         const int dx = dirs[k][0], dy = dirs[k][1];
         const int lines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
-        hipLaunchKernelGGL(k_sgm_path, dim3(lines, n), dim3(threads), 0, stream, b.C, b.S, g, dx, dy, P1, P2, k == 0 ? 1 : 0);
+        if (wave_paths && aligned && g.D <= 256) {
+            const dim3 wgrid((lines + 3) / 4, n);
+            const int first = k == 0 ? 1 : 0;
+            switch (npl) {
+                case 1: hipLaunchKernelGGL((k_sgm_path_w<1, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
+                case 2: hipLaunchKernelGGL((k_sgm_path_w<2, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
+                case 3: hipLaunchKernelGGL((k_sgm_path_w<3, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
+                default: hipLaunchKernelGGL((k_sgm_path_w<4, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
+            }
+        } else {
+            hipLaunchKernelGGL(k_sgm_path, dim3(lines, n), dim3(threads), 0, stream, b.C, b.S, g, dx, dy, P1, P2, k == 0 ? 1 : 0);
+        }
     }
     const bool speckle = speckleWindowSize > 0 && speckleRange >= 0;
     const size_t lds = (size_t)g.W * (8 + 2 + 2 + 2);

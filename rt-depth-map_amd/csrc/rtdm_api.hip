@@ -734,7 +734,7 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     void** ptrs[] = {(void**)&sg->dInL, (void**)&sg->dInR, (void**)&sg->dOut, (void**)&sg->b.gl, (void**)&sg->b.gr,
                      (void**)&sg->b.pix, (void**)&sg->b.C, (void**)&sg->b.S, (void**)&sg->b.label, (void**)&sg->b.size,
                      (void**)&sg->b.runs, (void**)&sg->b.rowcnt, (void**)&sg->b.headmap};
-    const size_t sizes[] = {px, px, px * 2, px, px, vol, vol * 2, vol * 2, px * 4, px * 4, px * 4,
+    const size_t sizes[] = {px, px, px * 2, px * 8, px * 8, vol, vol * 2, vol * 2, px * 4, px * 4, px * 4,
                             (size_t)max_batch * max_height * 4, px * 2};
     for (int i = 0; i < 13 && e == hipSuccess; ++i) e = hipMalloc(ptrs[i], sizes[i]);
     if (e != hipSuccess) {

@@ -84,7 +84,7 @@ void launch_morph_open_close(Plane8 in, Plane8W out, uint8_t* tmp0, uint8_t* tmp
 // SGM-8 (BASELINE config 5).  Cost volumes live on the column domain [x0, x0+W1).
 struct SGMGeom { int W, H, D, minD, x0, W1; };
 struct SGMBuffers {
-    uint8_t *gl, *gr;        // gradient images           [n][H][W]
+    uint8_t *gl, *gr;        // Birchfield-Tomasi bounds of gradient and intensity, 2 x uchar4 per pixel  [n][H][W]
     uint8_t* pix;            // pixel cost                 [n][H][W1][D]
     uint16_t *C, *S;         // block cost, aggregated     [n][H][W1][D]
     int32_t *label, *size, *rowcnt; uint32_t* runs; int16_t* headmap;   // speckle filter workspace
