@@ -141,10 +141,12 @@ typedef struct rtdm_sgm_params {
     int speckleWindowSize; /* <= 0 disables */
     int speckleRange;      /* multiplied by 16, as cv::StereoSGBM does */
     int disp12MaxDiff;     /* < 0 disables */
+    int paths;             /* 8 (BASELINE config 5) or 5: the directions of cv::StereoSGBM's default MODE_SGBM, which is the
+                            * mode sgbm-sw.cpp:15 creates (left, right, down, down-right, down-left) */
 } rtdm_sgm_params;
 typedef struct rtdm_sgm rtdm_sgm;
 /* blockSize as given, minD 0, P1 600, P2 2400 (sgbm-sw.cpp:17-18), uniqueness 10, speckle 100/32,
- * disp12MaxDiff 1 (the literals main.cpp:134-135 passes to the BM matcher). */
+ * disp12MaxDiff 1 (the literals main.cpp:134-135 passes to the BM matcher), 8 paths. */
 void rtdm_sgm_default_params(rtdm_sgm_params* p, int numDisparities, int blockSize);
 int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height, int max_batch,
                     int device, rtdm_sgm** out);

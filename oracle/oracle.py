@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_build", "librtdm_oracle.so")
 
 class SGMParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("blockSize", "minDisparity", "numDisparities", "P1", "P2", "uniquenessRatio",
-                                       "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
+                                       "speckleWindowSize", "speckleRange", "disp12MaxDiff", "paths")]
 
 
 class BMParams(C.Structure):
@@ -76,6 +76,8 @@ def lib():
         L.orc_sgm_block_cost.restype = None
         L.orc_sgm_aggregate.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
         L.orc_sgm_aggregate.restype = None
+        L.orc_sgm_aggregate_paths.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
+        L.orc_sgm_aggregate_paths.restype = None
         L.orc_sgm_select.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i16p, C.c_size_t]
         L.orc_sgm_select.restype = None
         L.orc_depth_stats.argtypes = [i16p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, C.c_size_t,
@@ -198,10 +200,10 @@ def morph_open_close(img):
 
 
 def make_sgm_params(blockSize=5, minDisparity=0, numDisparities=128, P1=600, P2=2400, uniquenessRatio=10,
-                    speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1):
+                    speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1, paths=8):
     """Defaults: P1/P2 from sgbm-sw.cpp:17-18, the rest the literals main.cpp:134-135 uses for the BM matcher."""
     return SGMParams(blockSize, minDisparity, numDisparities, P1, P2, uniquenessRatio, speckleWindowSize,
-                     speckleRange, disp12MaxDiff)
+                     speckleRange, disp12MaxDiff, paths)
 
 
 def sgm_compute(left, right, **kw):
@@ -226,7 +228,7 @@ def sgm_stages(left, right, **kw):
     L = lib()
     L.orc_sgm_pixel_cost(_p(left, C.c_uint8), W, _p(right, C.c_uint8), W, W, H, minD, D, _p(pix, C.c_uint16))
     L.orc_sgm_block_cost(_p(pix, C.c_uint16), W1, H, D, p.blockSize, _p(Cc, C.c_uint16))
-    L.orc_sgm_aggregate(_p(Cc, C.c_uint16), W1, H, D, p.P1, p.P2, _p(S, C.c_uint16))
+    L.orc_sgm_aggregate_paths(_p(Cc, C.c_uint16), W1, H, D, p.P1, p.P2, 5 if p.paths == 5 else 8, _p(S, C.c_uint16))
     return pix, Cc, S
 
 

@@ -102,12 +102,15 @@ typedef struct orc_sgm_params {
     int speckleWindowSize;
     int speckleRange;       /* multiplied by 16 for filterSpeckles, as cv::StereoSGBM does        */
     int disp12MaxDiff;      /* < 0 disables the left-right check                                  */
+    int paths;              /* 8 (BASELINE config 5; 0 means 8) or 5 = the directions of cv::StereoSGBM's default
+                             * MODE_SGBM, the mode sgbm-sw.cpp:15 gets: left, right, down, down-right, down-left */
 } orc_sgm_params;
 
 void orc_sgm_pixel_cost(const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep, int W, int H,
                         int minD, int D, uint16_t* cost);
 void orc_sgm_block_cost(const uint16_t* pix, int W1, int H, int D, int blockSize, uint16_t* C);
-void orc_sgm_aggregate(const uint16_t* C, int W1, int H, int D, int P1, int P2, uint16_t* S);
+void orc_sgm_aggregate(const uint16_t* C, int W1, int H, int D, int P1, int P2, uint16_t* S);            /* 8 paths */
+void orc_sgm_aggregate_paths(const uint16_t* C, int W1, int H, int D, int P1, int P2, int paths, uint16_t* S);
 void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int uniquenessRatio, int disp12MaxDiff,
                     int16_t* disp, size_t dstep_elems);
 int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep,

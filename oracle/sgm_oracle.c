@@ -147,12 +147,18 @@ static void sgm_path(const uint16_t* C, int W, int H, int D, int dx, int dy, int
     free(cur); free(prev);
 }
 
-void orc_sgm_aggregate(const uint16_t* C, int W, int H, int D, int P1, int P2, uint16_t* S)
+void orc_sgm_aggregate_paths(const uint16_t* C, int W, int H, int D, int P1, int P2, int paths, uint16_t* S)
 {
     static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1}};
     memset(S, 0, sizeof(uint16_t) * (size_t)W * H * D);
-    for (int k = 0; k < 8; ++k) sgm_path(C, W, H, D, dirs[k][0], dirs[k][1], P1, P2, S);
+    for (int k = 0; k < 8; ++k) {
+        if (paths == 5 && dirs[k][1] < 0) continue;        /* MODE_SGBM: no path that runs upwards */
+        sgm_path(C, W, H, D, dirs[k][0], dirs[k][1], P1, P2, S);
+    }
 }
+
+void orc_sgm_aggregate(const uint16_t* C, int W, int H, int D, int P1, int P2, uint16_t* S)
+{ orc_sgm_aggregate_paths(C, W, H, D, P1, P2, 8, S); }
 
 void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int uniquenessRatio, int disp12MaxDiff,
                     int16_t* disp, size_t dstep)
@@ -204,6 +210,7 @@ int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, con
     const int D = p->numDisparities, minD = p->minDisparity;
     if (D <= 0 || D % 16 != 0 || p->blockSize < 1 || (p->blockSize & 1) == 0) return ORC_ERR_BAD_PARAM;
     if (p->P1 <= 0 || p->P2 <= p->P1 || p->uniquenessRatio < 0 || p->uniquenessRatio > 100) return ORC_ERR_BAD_PARAM;
+    if (p->paths != 0 && p->paths != 5 && p->paths != 8) return ORC_ERR_BAD_PARAM;
     const int W1 = (W + imin(minD, 0)) - imax(minD + D, 0);
     if (W1 <= 0) {
         for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) disp[(size_t)y * (dstep_bytes / 2) + x] = (int16_t)((minD - 1) * 16);
@@ -215,7 +222,7 @@ int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, con
     uint16_t* S = (uint16_t*)malloc(vol * 2);
     orc_sgm_pixel_cost(L, lstep, R, rstep, W, H, minD, D, pix);
     orc_sgm_block_cost(pix, W1, H, D, p->blockSize, C);
-    orc_sgm_aggregate(C, W1, H, D, p->P1, p->P2, S);
+    orc_sgm_aggregate_paths(C, W1, H, D, p->P1, p->P2, p->paths == 5 ? 5 : 8, S);
     orc_sgm_select(S, W, H, D, minD, p->uniquenessRatio, p->disp12MaxDiff, disp, dstep_bytes / 2);
     if (p->speckleWindowSize > 0 && p->speckleRange >= 0)
         orc_filter_speckles(disp, dstep_bytes / 2, W, H, (minD - 1) * 16, p->speckleWindowSize, 16 * p->speckleRange);

@@ -32,7 +32,7 @@ class HsvRange(C.Structure):
 
 class SGMParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("blockSize", "minDisparity", "numDisparities", "P1", "P2", "uniquenessRatio",
-                                       "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
+                                       "speckleWindowSize", "speckleRange", "disp12MaxDiff", "paths")]
 
 
 class BMParams(C.Structure):

@@ -389,7 +389,7 @@ static void launch_select(int nch, dim3 grid, size_t lds, hipStream_t stream, co
 }
 
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
-                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int n, hipStream_t stream)
+                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream)
 {
     dim3 blk(256);
     hipLaunchKernelGGL(k_sgm_bounds, dim3((g.W + 255) / 256, g.H, 2 * n), blk, 0, stream, L, R, (uint2*)b.gl, (uint2*)b.gr, g.W, g.H, n);
@@ -414,6 +414,7 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     const bool aligned = (((size_t)b.C | (size_t)b.S) & 7) == 0;
     for (int k = 0; k < 8; ++k) {
         const int dx = dirs[k][0], dy = dirs[k][1];
+        if (paths == 5 && dy < 0) continue;          // MODE_SGBM's five directions: nothing runs upwards
         const int lines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
         if (wave_paths && aligned && g.D <= 256) {
             const dim3 wgrid((lines + 3) / 4, n);

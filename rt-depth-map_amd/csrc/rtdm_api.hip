@@ -709,7 +709,7 @@ void rtdm_sgm_default_params(rtdm_sgm_params* p, int numDisparities, int blockSi
 {
     if (!p) return;
     p->blockSize = blockSize; p->minDisparity = 0; p->numDisparities = numDisparities; p->P1 = 600; p->P2 = 2400;
-    p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32; p->disp12MaxDiff = 1;
+    p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32; p->disp12MaxDiff = 1; p->paths = 8;
 }
 
 int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height, int max_batch, int device, rtdm_sgm** out)
@@ -719,6 +719,7 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     const rtdm_sgm_params& p = *params;
     if (p.numDisparities <= 0 || p.numDisparities % 16 != 0 || p.blockSize < 1 || (p.blockSize & 1) == 0) return RTDM_ERR_BAD_PARAM;
     if (p.P1 <= 0 || p.P2 <= p.P1 || p.uniquenessRatio < 0 || p.uniquenessRatio > 100) return RTDM_ERR_BAD_PARAM;
+    if (p.paths != 5 && p.paths != 8) return RTDM_ERR_BAD_PARAM;
     if (max_width <= 0 || max_height <= 0 || max_batch <= 0) return RTDM_ERR_BAD_SIZE;
     if (p.numDisparities > 256 || max_width > 4096) return RTDM_ERR_UNSUPPORTED;
     // the aggregated volume is uint16: 8 paths x (block cost + P2) must fit (pixel cost <= 30 + 63)
@@ -767,7 +768,7 @@ static int sgm_chunk(rtdm_sgm* sg, int n, Plane8 L, Plane8 R, int W, int H, Plan
     g.W1 = (W + std::min(g.minD, 0)) - g.x0;
     if (g.W1 <= 0) { launch_fill16(disp, 0, W, 0, H, n, (g.minD - 1) * 16, s); return RTDM_OK; }
     launch_sgm(L, R, disp, g, sg->b, p.blockSize, p.P1, p.P2, p.uniquenessRatio, p.disp12MaxDiff, p.speckleWindowSize,
-               p.speckleRange, n, s);
+               p.speckleRange, p.paths, n, s);
     HIPC(hipGetLastError());
     return RTDM_OK;
 }

@@ -90,7 +90,7 @@ struct SGMBuffers {
     int32_t *label, *size, *rowcnt; uint32_t* runs; int16_t* headmap;   // speckle filter workspace
 };
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
-                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int n, hipStream_t stream);
+                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream);
 
 // Depth statistics after the matcher (estimator.cpp:75-77, 206-263).  q = the 4x4 reprojection matrix Q, row major.
 struct DepthQ { double q[16]; };

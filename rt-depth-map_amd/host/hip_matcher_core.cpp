@@ -120,12 +120,12 @@ int HIPObjectsCore::estimateFrame(HIPMatcherCore& matcher, HIPRectifierCore& rec
 }
 
 HIPSGMCore::HIPSGMCore(int blockSize, int minDisparity, int numOfDisparities, int uniquenessRatio, int speckleWindowSize,
-                       int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device)
+                       int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device, int paths)
 {
     rtdm_sgm_params p;
     rtdm_sgm_default_params(&p, numOfDisparities, blockSize);     // P1 = 8*3*5*5, P2 = 32*3*5*5 (sgbm-sw.cpp:17-18)
     p.minDisparity = minDisparity; p.uniquenessRatio = uniquenessRatio; p.speckleWindowSize = speckleWindowSize;
-    p.speckleRange = speckleRange; p.disp12MaxDiff = disp12MaxDiff;
+    p.speckleRange = speckleRange; p.disp12MaxDiff = disp12MaxDiff; p.paths = paths;
     status_ = rtdm_sgm_create(&p, maxWidth, maxHeight, 1, device, &sg_);
     if (status_ != RTDM_OK) std::fprintf(stderr, "HIPSemiGlobalMatcher: %s\n", rtdm_strerror(status_));
 }

@@ -61,11 +61,12 @@ private:
 
 // SWSemiGlobalMatcher counterpart (/root/reference/include/stereo-matcher/sgbm-sw.h:24-37): the same seven
 // constructor arguments in the same order plus the frame size; P1 = 600 and P2 = 2400 as sgbm-sw.cpp:17-18
-// hard-codes them; setROI1/2 are no-ops there too.  8-path aggregation (BASELINE config 5).
+// hard-codes them; setROI1/2 are no-ops there too.  paths = 8 (BASELINE config 5) or 5: the directions of
+// cv::StereoSGBM's default MODE_SGBM, which is what sgbm-sw.cpp:15 creates -- the adapter sgbm-hip.cpp passes 5.
 class HIPSGMCore {
 public:
     HIPSGMCore(int blockSize, int minDisparity, int numOfDisparities, int uniquenessRatio, int speckleWindowSize,
-               int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device = 0);
+               int speckleRange, int disp12MaxDiff, int maxWidth, int maxHeight, int device = 0, int paths = 8);
     ~HIPSGMCore();
     HIPSGMCore(const HIPSGMCore&) = delete;
     HIPSGMCore& operator=(const HIPSGMCore&) = delete;

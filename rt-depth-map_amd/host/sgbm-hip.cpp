@@ -9,7 +9,7 @@ HIPSemiGlobalMatcher::HIPSemiGlobalMatcher(int blockSize, int minDisparity, int 
 		int speckleWindowSize, int speckleRange, int disp12MaxDiff, int width, int height)
 {
 	core = new rtdm::HIPSGMCore(blockSize, minDisparity, numOfDisparities, uniquenessRatio, speckleWindowSize,
-			speckleRange, disp12MaxDiff, width, height);
+			speckleRange, disp12MaxDiff, width, height, 0, 5 /* the five directions of StereoSGBM's default mode */);
 }
 
 HIPSemiGlobalMatcher::~HIPSemiGlobalMatcher()

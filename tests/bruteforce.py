@@ -216,7 +216,7 @@ def _bt_bounds(a):
     return a, np.minimum(np.minimum(left, right), a), np.maximum(np.maximum(left, right), a)
 
 
-def sgm_volumes(L, R, D, minD=0, blockSize=5, P1=600, P2=2400):
+def sgm_volumes(L, R, D, minD=0, blockSize=5, P1=600, P2=2400, paths=8):
     H, W = L.shape
     x0, x1 = max(minD + D, 0), W + min(minD, 0)
     W1 = x1 - x0
@@ -238,6 +238,8 @@ def sgm_volumes(L, R, D, minD=0, blockSize=5, P1=600, P2=2400):
             C += pix[np.clip(yy + dy, 0, H - 1)[:, None], np.clip(xx + dx, 0, W1 - 1)[None, :]]
     S = np.zeros_like(C)
     for dx, dy in ((1, 0), (-1, 0), (0, 1), (0, -1), (1, 1), (-1, 1), (1, -1), (-1, -1)):
+        if paths == 5 and dy < 0:                  # the five directions of the library's default mode: none runs upwards
+            continue
         Lr = np.zeros_like(C)
         ys = range(H) if dy >= 0 else range(H - 1, -1, -1)
         xs_ = range(W1) if dx >= 0 else range(W1 - 1, -1, -1)
@@ -258,7 +260,7 @@ def sgm_volumes(L, R, D, minD=0, blockSize=5, P1=600, P2=2400):
 
 
 def sgm(L, R, numDisparities=32, minDisparity=0, blockSize=5, P1=600, P2=2400, uniquenessRatio=10,
-        speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1):
+        speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1, paths=8):
     H, W = L.shape
     D, minD = numDisparities, minDisparity
     INV = (minD - 1) * 16
@@ -266,7 +268,7 @@ def sgm(L, R, numDisparities=32, minDisparity=0, blockSize=5, P1=600, P2=2400, u
     x0, x1 = max(minD + D, 0), W + min(minD, 0)
     if x1 - x0 <= 0:
         return out.astype(np.int16)
-    _, _, S = sgm_volumes(L, R, D, minD, blockSize, P1, P2)
+    _, _, S = sgm_volumes(L, R, D, minD, blockSize, P1, P2, paths)
     for y in range(H):
         d2 = [minD - 1] * W; c2 = [None] * W
         for x in range(x0, x1):

@@ -75,7 +75,8 @@ def test_random_sgm_configuration(pkg, oracle, synth, seed):
     W, H = int(rng.integers(D + 30, D + 150)), int(rng.integers(12, 60))
     kw = dict(blockSize=bs, minDisparity=minD, uniquenessRatio=int(rng.choice([10, 0, 30])),
               speckleWindowSize=int(rng.choice([100, 0, 15])), speckleRange=int(rng.choice([32, 1, 2])),
-              disp12MaxDiff=int(rng.choice([1, -1, 0])), P1=int(rng.choice([600, 8, 100])), P2=int(rng.choice([2400, 700, 3000])))
+              disp12MaxDiff=int(rng.choice([1, -1, 0])), P1=int(rng.choice([600, 8, 100])), P2=int(rng.choice([2400, 700, 3000])),
+              paths=int(rng.choice([8, 5])))
     L, R = synth.make_pair(synth.STREAM_SEED + 7000 + seed, W, H, D)
     want = oracle.sgm_compute(L, R, numDisparities=D, **kw)
     m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, **kw)

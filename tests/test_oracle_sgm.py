@@ -28,6 +28,16 @@ def test_full_sgm_matches_bruteforce(oracle, synth, kw):
     assert (a != ((kw.get("minDisparity", 0) - 1) * 16)).any()
 
 
+def test_five_path_mode_matches_bruteforce(oracle, synth):
+    # paths=5: the directions of cv::StereoSGBM's default MODE_SGBM (what sgbm-sw.cpp:15 creates): no upward path
+    L, R = synth.make_pair(synth.STREAM_SEED + 610, 64, 22, 16)
+    _, _, S5 = oracle.sgm_stages(L, R, numDisparities=16, paths=5)
+    _, _, S8 = oracle.sgm_stages(L, R, numDisparities=16)
+    _, _, b5 = bf.sgm_volumes(L, R, 16, paths=5)
+    assert np.array_equal(S5, b5) and not np.array_equal(S5, S8) and (S5 <= S8).all()
+    assert np.array_equal(oracle.sgm_compute(L, R, numDisparities=16, paths=5), bf.sgm(L, R, numDisparities=16, paths=5))
+
+
 def test_kat_shifted_pair_recovers_shift(oracle, synth):
     W, H, D, k = 160, 60, 32, 9
     y, x = np.mgrid[0:H, 0:W]

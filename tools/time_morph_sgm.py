@@ -37,4 +37,13 @@ got = dD[0].cpu().numpy()
 out["sgm8_1280x720_d128_bs5"] = {"ms_per_pair": round(dt / n * 1e3, 3), "pairs_per_s": round(n / dt, 1), "cpu_oracle_s_per_pair_1thread": round(tc, 2),
                                   "bit_exact_vs_oracle": bool(np.array_equal(got, want)), "max_abs_diff_x16": int(np.abs(got.astype(int) - want).max()),
                                   "pixels_differing_pct": float((got != want).mean() * 100), "valid_fraction": float((got != -16).mean())}
+# --- the reference's own mode: 5 directions ------------------------------------------------------
+sg5 = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, max_batch=n, paths=5)
+for _ in range(2): sg5.compute_device(dL, dR, dD, st)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(5): sg5.compute_device(dL, dR, dD, st)
+torch.cuda.synchronize(); dt5 = (time.perf_counter() - t0) / 5
+want5 = orc.sgm_compute(L, R, numDisparities=D, paths=5)
+out["sgm5_1280x720_d128_bs5"] = {"ms_per_pair": round(dt5 / n * 1e3, 3), "pairs_per_s": round(n / dt5, 1),
+                                  "bit_exact_vs_oracle": bool(np.array_equal(dD[0].cpu().numpy(), want5))}
 print(json.dumps(out, indent=1))
