@@ -1,23 +1,54 @@
 #!/bin/bash
-# HBM traffic of the hot-path kernels (run on the GPU box; separate --pmc passes, no tracing domains).
+# HBM traffic and SQ activity of the hot-path kernels (run on the GPU box).  Counters are collected in passes of
+# their own (no tracing domains): FETCH_SIZE and WRITE_SIZE cannot share a pass; the SQ set fills its 8 slots.
+# Writes gpurun_out/pmc_traffic/{summary.txt,traffic.json}; copy them to profiles/rNN_pmc_traffic_rocprofv3.txt / .json.
 cd /tmp && export TMPDIR=/tmp
-OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_traffic
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- $GRAFT_REPO_ROOT/tools/ubench_fetch > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $GRAFT_REPO_ROOT/tools/ubench_fetch > /dev/null 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_fetch -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --batch 64 --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bench_write -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --batch 64 --no-cpu-baseline > /dev/null 2>&1
+B="--steps 2 --warmup 1 --batch 64 --no-cpu-baseline"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- $R/tools/ubench_fetch > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $R/tools/ubench_fetch > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_fetch -- python $R/bench.py $B > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bench_write -- python $R/bench.py $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
+    --output-format csv -d $OUT/bench_sq -- python $R/bench.py $B > /dev/null 2>&1
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, json, re
 def load(d):
     agg = collections.defaultdict(list)
     for f in glob.glob("$OUT/" + d + "/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            agg[(r["Kernel_Name"].split("(")[0][-48:], r["Counter_Name"])].append(float(r["Counter_Value"]))
+            name = r["Kernel_Name"].split("(")[0]
+            agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
     return agg
-for d in ("cal_fetch", "cal_write", "bench_fetch", "bench_write"):
-    print("==", d)
+lines = []
+data = {}
+for d in ("cal_fetch", "cal_write", "bench_fetch", "bench_write", "bench_sq"):
+    lines.append("== " + d)
     for (k, c), v in sorted(load(d).items()):
         if "rtdm" in k or "k_" in k:
-            print("%-50s %-11s n=%3d mean=%14.1f" % (k, c, len(v), sum(v) / len(v)))
+            lines.append("%-60s %-20s n=%3d mean=%16.1f" % (k[-60:], c, len(v), sum(v) / len(v)))
+            if d.startswith("bench"):
+                key = re.sub(r"^void ", "", k).replace("rtdm::", "").replace(", ", ",")
+                data.setdefault(key, {})[c] = sum(v) / len(v)
+open("$OUT/summary.txt", "w").write("\n".join(lines) + "\n")
+PAIRS = 64
+out = {"source": "tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes)", "pairs_per_launch": PAIRS, "workload": "1280x720 d=64 9x9",
+       "fetch_correction": 2.0, "unit": "KB (FETCH_SIZE reads 1/2 on gfx950, calibrated with tools/ubench_fetch; WRITE_SIZE exact)",
+       "sq_unit": "quad-cycles summed over all waves / SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs", "kernels": {}}
+for k, c in sorted(data.items()):
+    e = dict(c)
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        e["hbm_bytes_per_pair"] = int((2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / PAIRS)
+    if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
+        # SIMD-cycles available = clocks x 256 CUs x 4 SIMDs; a VALU instruction occupies its SIMD for the counted quad-cycles x 4
+        simd_cycles = c["GRBM_GUI_ACTIVE"] / 8 * 256 * 4
+        e["valu_busy_frac_of_simd_cycles"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles, 4)
+        e["valu_insts_per_pixel"] = round(c["SQ_INSTS_VALU"] * 64 / (PAIRS * 1280 * 720), 1) if "SQ_INSTS_VALU" in c else None
+        if c.get("SQ_WAVE_CYCLES"):
+            e["wave_cycle_split"] = {n: round(c.get(n, 0) / c["SQ_WAVE_CYCLES"], 4) for n in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")}
+    out["kernels"][k] = e
+json.dump(out, open("$OUT/traffic.json", "w"), indent=1)
+print("\n".join(lines[-40:]))
 PY
