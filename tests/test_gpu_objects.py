@@ -58,6 +58,21 @@ def test_detection_matches_the_oracle(pkg, oracle, seed):
     det.close()
 
 
+@pytest.mark.parametrize("W,H", [(1, 1), (2, 2), (5, 3), (11, 40), (300, 12), (23, 23)])
+def test_tiny_and_degenerate_crops(pkg, oracle, W, H):
+    # all foreground, all background, a checkerboard (8-connected into one component), random
+    rng = np.random.default_rng(W * 100 + H)
+    yy, xx = np.mgrid[0:H, 0:W]
+    det = pkg.HIPObjectDetector(W, H)
+    for mask in (np.ones((H, W), bool), np.zeros((H, W), bool), (yy + xx) % 2 == 0, rng.random((H, W)) < 0.5):
+        rgb = paint(mask, rng)
+        for zb in (True, False):
+            boxes, roi, out = det.detect(rgb, min_area=1, zero_border=zb, max_boxes=512)
+            _, want_out, want = oracle_detect(oracle, rgb, 1, zb)
+            assert np.array_equal(out, want_out) and boxes == want, (W, H, zb, boxes, want)
+    det.close()
+
+
 def test_hsv_thresholds_other_than_the_default(pkg, oracle):
     rng = np.random.default_rng(9)
     rgb = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)

@@ -81,6 +81,22 @@ def test_raw_frames_to_disparity_in_one_call(pkg, oracle, synth, res, D, w):
     m.close(); r.close()
 
 
+def test_one_pixel_crop_and_tiny_frame(pkg, oracle):
+    rng = np.random.default_rng(11)
+    W, H = 7, 5
+    maps = []
+    for k in range(2):
+        maps.append(np.stack([rng.integers(-2, W + 1, (H, W)), rng.integers(-2, H + 1, (H, W))], -1).astype(np.int16))
+        maps.append(rng.integers(0, 1024, (H, W)).astype(np.uint16))
+    L = rng.integers(0, 256, (H, W, 3), dtype=np.uint8); R = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    for roi in ((3, 2, 1, 1), (0, 0, W, H), (6, 4, 1, 1)):
+        r = pkg.HIPRectifier(*maps, roi=roi)
+        gl, gr = r.gray(L, R)
+        assert np.array_equal(gl, oracle.rectify_gray(L, maps[0], maps[1], roi)) and np.array_equal(gr, oracle.rectify_gray(R, maps[2], maps[3], roi))
+        assert np.array_equal(r.rgb(R, 0), oracle.rectify_rgb(R, maps[0], maps[1], roi))
+        r.close()
+
+
 def test_argument_errors(pkg, oracle):
     c, maps = ru.maps(oracle, "320x240")
     with pytest.raises(pkg.binding.RtdmError):
