@@ -331,43 +331,57 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     const uint16_t* crow = cost + ((size_t)f * g.H + y) * g.Ws;
     Short8 d8, c8;
+    // per-thread column masks (bit k = column x0 + k): inside the image / allowed to vote / inside the valid rectangle
+    const auto span = [&](int lo, int hi) -> unsigned {
+        const int a = min(max(lo - x0, 0), 8), b = min(max(hi - x0, 0), 8);
+        return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
+    };
+    const unsigned inimg = span(0, W), votem = span(minX1, maxX1), keepm = span(g.vx0, g.vx1);
+    unsigned im = 0;                                                  // bit k: d8.v[k] is a disparity (not INV)
     if (active) {
         d8 = *(const Short8*)(row + x0);
         c8 = *(const Short8*)(crow + x0);
-        if (x0 + 8 > W)                                   // ragged last chunk: the plane's padding columns do not exist
-            for (int k = 0; k < 8; ++k) if (x0 + k >= W) d8.v[k] = (int16_t)INV;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (!((inimg >> k) & 1)) d8.v[k] = (int16_t)INV;          // ragged last chunk: padding columns do not exist
+            im |= (unsigned)(d8.v[k] != INV) << k;
+        }
         *(Short8*)(snap + x0) = d8;
         const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
         ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
     }
     __syncthreads();
-    if (active) {
+    {
+        const unsigned vm = im & votem;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+            if (!((vm >> k) & 1)) continue;
             const int x = x0 + k, d = d8.v[k];
-            if (d == INV || x < minX1 || x >= maxX1) continue;
             const int x2 = x - ((d + 8) >> 4);
-            if (x2 < 0 || x2 >= W) continue;
+            if ((unsigned)x2 >= (unsigned)W) continue;
             atomicMin(&key[x2], ((uint32_t)(uint16_t)c8.v[k] << 16) | (uint32_t)x);
         }
     }
     __syncthreads();
     if (active) {
-        bool changed = false;
+        const unsigned chk = im & votem & keepm;                      // columns whose two matches are looked up
+        unsigned kill = im & ~keepm;                                  // outside the valid rectangle: always dropped
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
+            if (!((chk >> k) & 1)) continue;
             const int x = x0 + k, d = d8.v[k];
-            bool kill = (x < g.vx0 || x >= g.vx1);
-            if (!kill && d != INV && x >= minX1 && x < maxX1) {
-                const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
-                bool bad0 = false, bad1 = false;
-                if (xa >= 0 && xa < W) { const uint32_t q = key[xa]; if (q != ~0u) bad0 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
-                if (xb >= 0 && xb < W) { const uint32_t q = key[xb]; if (q != ~0u) bad1 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
-                kill = bad0 && bad1;
-            }
-            if (kill && d != INV) { d8.v[k] = (int16_t)INV; changed = true; }
+            const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
+            bool bad0 = false, bad1 = false;
+            if ((unsigned)xa < (unsigned)W) { const uint32_t q = key[xa]; if (q != ~0u) bad0 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
+            if ((unsigned)xb < (unsigned)W) { const uint32_t q = key[xb]; if (q != ~0u) bad1 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
+            kill |= (unsigned)(bad0 && bad1) << k;
         }
-        if (changed) *(Short8*)(row + x0) = d8;
+        if (kill) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if ((kill >> k) & 1) d8.v[k] = (int16_t)INV;
+            *(Short8*)(row + x0) = d8;
+            im &= ~kill;
+        }
         if (SPK) *(Short8*)(fin + x0) = d8;
     }
     if (!SPK) return;
@@ -375,14 +389,17 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     // ---- speckle init of the finished row (what spk_row_init does, on per-thread aggregates) ----
     int left = INV, right = INV;
     if (active) { if (x0 > 0) left = fin[x0 - 1]; if (x0 + 8 < W) right = fin[x0 + 8]; }
-    unsigned hm = 0;
+    // cb bit k (k = 0..8): columns x0+k-1 and x0+k are connected (both disparities, close enough)
+    unsigned cb = 0;
     if (active) {
+        cb |= (unsigned)conn(left, d8.v[0], INV, spkDiff);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int v = d8.v[k], pv = k ? (int)d8.v[k - 1] : left;
-            hm |= (unsigned)(v != INV && !conn(v, pv, INV, spkDiff)) << k;
-        }
+        for (int k = 1; k < 8; ++k) cb |= (unsigned)(abs((int)d8.v[k] - (int)d8.v[k - 1]) <= spkDiff) << k;
+        cb &= (im & (im << 1)) | 1u;                                  // bits 1..7 need both columns to be disparities
+        cb |= (unsigned)conn(d8.v[7], right, INV, spkDiff) << 8;
     }
+    const unsigned hm = im & ~cb & 0xffu;                             // run heads
+    unsigned lm = im & ~(cb >> 1) & 0xffu;                            // run ends
     const int agg = hm ? ((__builtin_popcount(hm) << 16) | (x0 + (31 - __builtin_clz(hm)) + 1)) : 0;
     int t = agg;
 #pragma unroll
@@ -397,23 +414,26 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[q]);
     if (!active) return;
     const int base = (f * g.H + y) * g.Ws;
+    const int hin = (run & 0xffff) - 1, cin = run >> 16;             // head and run count carried in from the left
     Short8 h8;
+    {
+        int h = hin;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int x = x0 + k, v = d8.v[k];
-        if ((hm >> k) & 1) run = (int)(((unsigned)run & 0xffff0000u) + 0x10000u) | (x + 1);
-        const int h = (run & 0xffff) - 1;
-        h8.v[k] = (int16_t)h;
-        if (v == INV) continue;
-        const int nv = k < 7 ? (int)d8.v[k + 1] : right;
-        if (conn(v, nv, INV, spkDiff)) continue;                 // not the last pixel of its run
-        const int len = x - h + 1;
-        label[base + h] = base + h;
-        size[base + h] = len;
-        runs[base + (run >> 16) - 1] = (uint32_t)h | ((uint32_t)len << 16);
+        for (int k = 0; k < 8; ++k) { if ((hm >> k) & 1) h = x0 + k; h8.v[k] = (int16_t)h; }
     }
     *(Short8*)(headmap + base + x0) = h8;
-    if (x0 + 8 >= W) rowcnt[f * g.H + y] = run >> 16;
+    while (lm) {                                                      // one trip per run that ends in this chunk
+        const int k = __builtin_ctz(lm);
+        lm &= lm - 1;
+        const unsigned hb = hm & ((2u << k) - 1u);                    // heads at or left of the end
+        const int h = hb ? x0 + (31 - __builtin_clz(hb)) : hin;
+        const int idx = cin + __builtin_popcount(hb);                 // 1-based index of this run in the row
+        const int len = x0 + k - h + 1;
+        label[base + h] = base + h;
+        size[base + h] = len;
+        runs[base + idx - 1] = (uint32_t)h | ((uint32_t)len << 16);
+    }
+    if (x0 + 8 >= W) rowcnt[f * g.H + y] = cin + __builtin_popcount(hm);
 }
 
 void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
