@@ -37,8 +37,14 @@ struct FastGeom {
     int x0, nx;          // output-column range [x0, x0+nx) handled by this kernel
     int rs;              // output rows per workgroup
     uint32_t lastmask;   // byte mask of the last (partial) window piece
-    int tiles;           // workgroups with blockIdx.x >= tiles do the border columns (rtdm_border.h)
-    int bgx, bgy;        // grid of that border work (0 x 0: none)
+    int tiles, strips;   // column tiles x row strips per frame
+    int bgx, bgy;        // grid of the border-column work per frame (rtdm_border.h; 0 x 0: none)
+    // 1-D launch grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so work is dealt in GROUPS of 8
+    // consecutive ids that are all tiles or all border work; the two kinds of groups are interleaved evenly
+    // (Bresenham).  Every XCD then gets the same share of both kinds whatever tiles / strips / batch are -- with a 3-D
+    // grid the share depended on gridDim.x mod 8 and the search ran up to 1.5x slower for unlucky shapes.
+    unsigned nfast, nborder;   // workgroups of each kind over the whole batch
+    unsigned gfast, gborder;   // groups of 8
 };
 
 template <int D, int NP>
@@ -112,21 +118,28 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
     constexpr int NG = C::NG, NR = C::NR, LWD = C::LWD, RWD = C::RWD, SLOT = C::SLOT, ITEMS = C::ITEMS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
-    if (blockIdx.x >= (unsigned)fg.tiles) {
+    const unsigned grp = blockIdx.x >> 3, slot = blockIdx.x & 7, ngroups = fg.gfast + fg.gborder;
+    const unsigned nb = (unsigned)(((unsigned long long)grp * fg.gborder) / ngroups);            // border groups before this one
+    if ((unsigned)(((unsigned long long)(grp + 1) * fg.gborder) / ngroups) > nb) {
         // border columns: latency-bound, so they ride in the same grid and overlap the VALU-bound tiles
-        const int id = (blockIdx.x - fg.tiles) * gridDim.y + blockIdx.y;
-        if (id < fg.bgx * fg.bgy) border_body<(D + 63) / 64>((unsigned char*)lds, Lp, Rp, disp, cost, g, bg, id % fg.bgx, id / fg.bgx, blockIdx.z);
+        const unsigned bi = nb * 8 + slot;
+        if (bi >= fg.nborder) return;
+        const unsigned per = (unsigned)(fg.bgx * fg.bgy), fr = bi / per, id = bi - fr * per;
+        border_body<(D + 63) / 64>((unsigned char*)lds, Lp, Rp, disp, cost, g, bg, (int)(id % fg.bgx), (int)(id / fg.bgx), (int)fr);
         return;
     }
+    const unsigned fi = (grp - nb) * 8 + slot;
+    if (fi >= fg.nfast) return;
+    const int b_tile = (int)(fi % fg.tiles), b_strip = (int)((fi / fg.tiles) % fg.strips), b_frame = (int)(fi / (fg.tiles * fg.strips));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int phi = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int x_tile = fg.x0 + blockIdx.x * 256;
+    const int x_tile = fg.x0 + b_tile * 256;
     const int x = x_tile + phi + 4 * lane;
     const bool active = x < fg.x0 + fg.nx;
-    const int ys0 = g.vy0 + blockIdx.y * fg.rs;
+    const int ys0 = g.vy0 + b_strip * fg.rs;
     const int ys1 = min(ys0 + fg.rs, g.vy1);
-    const int f = blockIdx.z;
+    const int f = b_frame;
     const int w = g.w, r = g.r, RING = g.w + 2;
     const uint8_t* Lb = Lp.base + (size_t)f * Lp.frame;
     const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
@@ -357,18 +370,17 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     strips = (nrows + fg.rs - 1) / fg.rs;
     size_t ldsb = (size_t)(g.w + 2) * C::SLOT * 4;
     BorderGeom bg = {};
-    fg.tiles = tiles; fg.bgx = fg.bgy = 0;
-    int extra = 0;
+    fg.tiles = tiles; fg.strips = strips; fg.bgx = fg.bgy = 0;
     if (fuse_border) {
         int lx0, lx1, rx0, rx1; size_t blds = 0;
         fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
-        if (border_geometry(g, lx0, lx1, rx0, rx1, &bg, &fg.bgx, &fg.bgy, &blds)) {
-            extra = (fg.bgx * fg.bgy + strips - 1) / strips;
-            ldsb = max(ldsb, blds);
-        }
+        if (border_geometry(g, lx0, lx1, rx0, rx1, &bg, &fg.bgx, &fg.bgy, &blds)) ldsb = max(ldsb, blds);
+        else fg.bgx = fg.bgy = 0;
     }
+    fg.nfast = (unsigned)tiles * strips * n; fg.nborder = (unsigned)(fg.bgx * fg.bgy) * n;
+    fg.gfast = (fg.nfast + 7) / 8; fg.gborder = (fg.nborder + 7) / 8;
     if (ldsb > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_search_fast<D, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-    hipLaunchKernelGGL((k_search_fast<D, NP>), dim3(tiles + extra, strips, n), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg, bg);
+    hipLaunchKernelGGL((k_search_fast<D, NP>), dim3((fg.gfast + fg.gborder) * 8), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg, bg);
 }
 
 // Instantiations: every (D, pieces) with D in {16,32,48,64,96,128,192,256} and 2..4 pieces (w = 5..15), plus
