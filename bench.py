@@ -113,7 +113,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=128, help="pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="pairs per step per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rccl-stream", type=int, default=0, metavar="FRAMES",
                     help="BASELINE config 4 instead of the headline: rank 0 owns FRAMES pairs, scatter -> compute -> gather "
