@@ -48,8 +48,10 @@ void orc_rgb2hsv(const uint8_t* rgb, size_t sstep, int W, int H, uint8_t* hsv, s
             const uint8_t* p = rgb + (size_t)y * sstep + 3 * (size_t)x;
             const int r = p[0], g = p[1], b = p[2];
             int v = b, vmin = b;
-            if (g > v) v = g; if (r > v) v = r;
-            if (g < vmin) vmin = g; if (r < vmin) vmin = r;
+            if (g > v) v = g;
+            if (r > v) v = r;
+            if (g < vmin) vmin = g;
+            if (r < vmin) vmin = r;
             const int diff = v - vmin;
             const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
             const int s = (diff * sdiv_tab[v] + (1 << 11)) >> 12;
@@ -105,7 +107,10 @@ int orc_external_boxes(const uint8_t* mask, size_t mstep, int W, int H, int zero
         stack[sp++] = (int)p0; lab[p0] = id; first[id] = (int)p0;
         while (sp) {
             const int p = stack[--sp], y = p / W, x = p - y * W;
-            if (x < x0) x0 = x; if (x > x1) x1 = x; if (y < y0) y0 = y; if (y > y1) y1 = y;
+            if (x < x0) x0 = x;
+            if (x > x1) x1 = x;
+            if (y < y0) y0 = y;
+            if (y > y1) y1 = y;
             if (x == 0 || y == 0 || x == W - 1 || y == H - 1) touches = 1;
             for (int dy = -1; dy <= 1; ++dy)
                 for (int dx = -1; dx <= 1; ++dx) {
@@ -143,7 +148,10 @@ void orc_union_box(const int* boxes, int n, int roi[4])
     int max_x = -1000000, max_y = -1000000, min_x = 1000000, min_y = 1000000;
     for (int i = 0; i < n; ++i) {
         const int x = boxes[4 * i], y = boxes[4 * i + 1], x2 = x + boxes[4 * i + 2], y2 = y + boxes[4 * i + 3];
-        if (x < min_x) min_x = x; if (y < min_y) min_y = y; if (x2 > max_x) max_x = x2; if (y2 > max_y) max_y = y2;
+        if (x < min_x) min_x = x;
+        if (y < min_y) min_y = y;
+        if (x2 > max_x) max_x = x2;
+        if (y2 > max_y) max_y = y2;
     }
     roi[0] = min_x; roi[1] = min_y; roi[2] = max_x - min_x; roi[3] = max_y - min_y;
 }
