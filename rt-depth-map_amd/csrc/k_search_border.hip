@@ -32,7 +32,7 @@ bool border_geometry(const BMGeom& g, int lx0, int lx1, int rx0, int rx1, Border
     bg.lx0 = lx0; bg.lx1 = max(lx1, lx0); bg.rx0 = rx0; bg.rx1 = max(rx1, rx0);
     const int nrows = g.vy1 - g.vy0;
     static int rs_env = 0;
-    if (!rs_env) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 32; if (rs_env < 8) rs_env = 32; }
+    if (!rs_env) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 128; if (rs_env < 8) rs_env = 128; }
     bg.rs = rs_env;
     bg.rsp = (g.D + g.w + 3 + 63 + 64) & ~3;       // + one chunk of slack for lanes with e >= D
     const int nch = (g.D + 63) / 64;
@@ -50,7 +50,7 @@ void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const
     bg.lx0 = lx0; bg.lx1 = max(lx1, lx0); bg.rx0 = rx0; bg.rx1 = max(rx1, rx0);
     const int nrows = g.vy1 - g.vy0;
     static int rs_env = 0;
-    if (!rs_env) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 32; if (rs_env < 8) rs_env = 32; }
+    if (!rs_env) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 128; if (rs_env < 8) rs_env = 128; }
     bg.rs = rs_env;
     bg.rsp = (g.D + g.w + 3 + 63 + 64) & ~3;       // + one chunk of slack for lanes with e >= D
     const int nch = (g.D + 63) / 64;

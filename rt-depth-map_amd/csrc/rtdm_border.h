@@ -29,8 +29,26 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+__device__ __forceinline__ int border_div_trunc(int num, int den)   // den > 0, |num| < 2^24: truncating quotient without the
+{                                                                    // 30-instruction integer division sequence
+    const unsigned an = (unsigned)(num < 0 ? -num : num);
+    unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
+    int rem = (int)an - (int)(q * (unsigned)den);
+    if (rem < 0) { --q; rem += den; }
+    if (rem < 0) { --q; rem += den; }
+    if (rem >= den) { ++q; rem -= den; }
+    if (rem >= den) { ++q; }
+    return num < 0 ? -(int)q : (int)q;
+}
+
 // Body of the border search for one workgroup (4 waves = 4 border columns x bg.rs rows).  bx/by = the
 // workgroup's column-group / strip index, f = frame.  No workgroup barrier inside.
+//
+// These workgroups share the SIMDs with the VALU-bound tile workgroups, so what they cost is their instruction count.
+// Per row visit and lane (= disparity e) the window's right-image bytes are R[rb(dx) + e] with rb(dx) = the clamped,
+// monotone sample base: the w bytes come out of 8-byte spans of the staged row by v_perm with WAVE-UNIFORM selectors
+// (which only depend on where the clamp bites), so a row visit is ceil(w/4) x (LDS reads, 2 v_alignbyte, v_perm,
+// v_sad_u8 on 4 bytes) instead of w x (byte read, index clamp, single-byte SAD).
 template <int NCH>
 __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
                                             const BMGeom& g, const BorderGeom& bg, int bx, int by, int f)
@@ -60,7 +78,31 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
     const int j0 = x - r;                                              // first sample index
     const int rbmin = min(max(g.rofs + j0, 0), W - D);
     const int rbmax = min(max(g.rofs + j0 + w - 1, 0), W - D);
-    const int span = rbmax - rbmin + D;                                // right bytes needed per row
+    const int ra = rbmin & ~3, rsh = rbmin & 3;                        // rows are staged from the aligned byte ra on
+    const int ndw = (w + 3) >> 2;                                      // window dwords (<= 6)
+    const int stage_dw = (rsh + NCH * 64 + (rbmax - rbmin) + 12 + 3) >> 2;   // dwords staged per right row (<= rsp / 4)
+    // wave-uniform gather plan: window dword q = bytes idx(4q) .. idx(4q+3) of the lane's span, idx(dx) = rb(dx) - rbmin
+    constexpr int MAXQ = 6;
+    int aq[MAXQ];
+    unsigned sel[MAXQ], capm[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const int p0 = min(max(g.rofs + j0 + 4 * q, 0), W - D) - rbmin;
+        aq[q] = p0 >> 2;
+        unsigned sv = 0, cm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dx = 4 * q + k;
+            const int pk = min(max(g.rofs + j0 + dx, 0), W - D) - rbmin - 4 * aq[q];      // 0..7
+            sv |= (dx < w ? (unsigned)pk : 0x0cu) << (8 * k);                              // 0x0c selects the constant 0
+            cm |= (dx < w ? (unsigned)g.cap : 0u) << (8 * k);
+        }
+        sel[q] = sv; capm[q] = cm;
+    }
+    // the lane's span starts at byte rsh + e of the staged row
+    int dwi[NCH], bsh[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { const int ba = rsh + lane + 64 * c; dwi[c] = ba >> 2; bsh[c] = ba & 3; }
 
     for (int i = lane; i < w * NCH * 64; i += 64) Hring[i] = 0;
     if (lane < w) Tring[lane] = 0;
@@ -77,26 +119,35 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
         const int nb = min(RB, nsteps - s0);
         for (int b = 0; b < nb; ++b) {
             const int row = ys0 - r + s0 + b;
-            const uint8_t* rrow = Rb + (size_t)row * Rp.pitch + rbmin;
-            for (int i = lane; i < span; i += 64) Rbuf[b * rsp + i] = rrow[i];
-            if (lane < w) Lbuf[b * 32 + lane] = Lb[(size_t)row * Lp.pitch + min(max(g.lofs + j0 + lane, 0), W - 1)];
+            const uint32_t* rrow = (const uint32_t*)(Rb + (size_t)row * Rp.pitch + ra);    // plane pitches are multiples of 64
+            uint32_t* rdst = (uint32_t*)(Rbuf + b * rsp);
+            for (int i = lane; i < stage_dw; i += 64) rdst[i] = rrow[i];
+            if (lane < 4 * ndw)
+                Lbuf[b * 32 + lane] = lane < w ? Lb[(size_t)row * Lp.pitch + min(max(g.lofs + j0 + lane, 0), W - 1)] : (uint8_t)0;
         }
         __builtin_amdgcn_wave_barrier();
         for (int b = 0; b < nb; ++b) {
             const int s = s0 + b;
-            int t = 0;
+            unsigned t = 0;
             unsigned h[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) h[c] = 0;
-            const uint8_t* lrow = Lbuf + b * 32;
-            const uint8_t* rrow = Rbuf + b * rsp + lane;              // staged span is padded: always in bounds
-#pragma unroll 3
-            for (int dx = 0; dx < w; ++dx) {
-                const unsigned lv = lrow[dx];
-                const int rbo = min(max(g.rofs + j0 + dx, 0), W - D) - rbmin;
-                t += abs((int)lv - g.cap);
+            const uint32_t* lrow = (const uint32_t*)(Lbuf + b * 32);
+            const uint32_t* rrow = (const uint32_t*)(Rbuf + b * rsp);
 #pragma unroll
-                for (int c = 0; c < NCH; ++c) h[c] = __builtin_amdgcn_sad_u8(lv, (unsigned)rrow[rbo + 64 * c], h[c]);
+            for (int q = 0; q < MAXQ; ++q) {
+                if (q < ndw) {
+                    const unsigned lv = lrow[q];
+                    t = __builtin_amdgcn_sad_u8(lv, capm[q], t);
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        const uint32_t* sp = rrow + dwi[c] + aq[q];
+                        const unsigned s0w = sp[0], s1w = sp[1], s2w = sp[2];
+                        const unsigned lo = __builtin_amdgcn_alignbyte(s1w, s0w, bsh[c]);
+                        const unsigned hi = __builtin_amdgcn_alignbyte(s2w, s1w, bsh[c]);
+                        h[c] = __builtin_amdgcn_sad_u8(__builtin_amdgcn_perm(hi, lo, sel[q]), lv, h[c]);
+                    }
+                }
             }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
@@ -108,8 +159,8 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
             }
             const int told = Tring[slot];
             __builtin_amdgcn_wave_barrier();
-            if (lane == 0) Tring[slot] = t;
-            tsum += t - told;
+            if (lane == 0) Tring[slot] = (int)t;
+            tsum += (int)t - told;
             slot = (slot + 1 == w) ? 0 : slot + 1;
             if (s < w - 1) continue;
 
@@ -124,7 +175,7 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
             const int m1 = (int)(k >> 8), a = (int)(k & 0xffu);
             bool fail = tsum < g.tex;
             if (g.uniq > 0) {
-                const int thresh = m1 + (m1 * g.uniq / 100);
+                const int thresh = m1 + (g.uniq < 512 ? border_div_trunc(m1 * g.uniq, 100) : m1 * g.uniq / 100);
                 bool hit = false;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -145,7 +196,7 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
                 int out = g.filtered;
                 if (!fail) {
                     const int den = pp + nn - 2 * m1 + abs(pp - nn);
-                    const int v = (D - a - 1 + g.minD) * 256 + (den != 0 ? (pp - nn) * 256 / den : 0) + 15;
+                    const int v = (D - a - 1 + g.minD) * 256 + (den != 0 ? border_div_trunc((pp - nn) * 256, den) : 0) + 15;
                     out = v >> 4;
                     if (g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)m1;
                 }
