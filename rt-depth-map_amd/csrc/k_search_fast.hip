@@ -20,6 +20,7 @@
 //   left-right check).  Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
 #include "rtdm_border.h"
 
+#include <cmath>
 #include <cstdlib>
 
 namespace rtdm {
@@ -347,11 +348,13 @@ static bool fast_range(const BMGeom& g, int* x0, int* nx)
 }
 
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
+int fast_strips_model(const BMGeom& g, int n);
 
 static int fast_np(const BMGeom& g) { return (g.w + 3) / 4; }
 
 template <int D, int NP>
-static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, bool fuse_border)
+static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, bool fuse_border,
+                       int strips_hint)
 {
     using C = FastCfg<D, NP>;
     FastGeom fg;
@@ -360,11 +363,16 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     fg.lastmask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
     const int nrows = g.vy1 - g.vy0;
     const int tiles = (fg.nx + 255) / 256;
-    // enough workgroups that the tail of the last scheduling round is small against the total
-    // (4 workgroups/CU resident => 1024 slots); a strip costs (w-1) extra entering-row visits
-    static int target_wgs = 0;
-    if (!target_wgs) { const char* e = getenv("RTDM_FAST_WGS"); target_wgs = e ? atoi(e) : 8192; if (target_wgs < 1) target_wgs = 8192; }
-    int strips = (target_wgs + tiles * n - 1) / (tiles * n);
+    // Row strips per frame: a strip pays w-1 extra (entering-only, ~half price) row visits, a long workgroup leaves a long
+    // tail in the last scheduling round (4 workgroups/CU resident => 1024 slots).  With K = tiles*n/1024 rounds per strip
+    // the time is ~ (nrows/strips + h)(K*strips + 1/2), h = (w-1)/2, minimal at strips = sqrt(nrows / ((w-1) K)).
+    // RTDM_FAST_WGS=<total workgroups> overrides (sweeps: tools/sweep_strips.sh, tools/sweep_wgs_small.py).
+    static int target_wgs = -1;
+    if (target_wgs < 0) { const char* e = getenv("RTDM_FAST_WGS"); target_wgs = e ? atoi(e) : 0; }
+    int strips;
+    if (strips_hint > 0) strips = strips_hint;                      // measured choice (rtdm_api.hip, tune_strips)
+    else if (target_wgs > 0) strips = (target_wgs + tiles * n - 1) / (tiles * n);
+    else strips = fast_strips_model(g, n);
     strips = max(1, min(strips, (nrows + 15) / 16));
     fg.rs = (nrows + strips - 1) / strips;
     strips = (nrows + fg.rs - 1) / fg.rs;
@@ -401,10 +409,20 @@ bool fast_search_supported(const BMGeom& g)
     return false;
 }
 
-void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, bool fuse_border)
+int fast_strips_model(const BMGeom& g, int n)
+{
+    int x0 = 0, nx = 0;
+    if (!fast_range(g, &x0, &nx)) return 1;
+    const int tiles = (nx + 255) / 256, nrows = g.vy1 - g.vy0;
+    const int s = (int)(sqrtf((float)nrows * 1024.0f / ((float)(g.w - 1) * (float)tiles * (float)n)) + 0.5f);
+    return max(1, min(s, (nrows + 15) / 16));
+}
+
+void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, bool fuse_border,
+                        int strips_hint)
 {
     const int np = fast_np(g);
-#define X(DD, PP) if (g.D == DD && np == PP) { launch_one<DD, PP>(Lp, Rp, disp, cost, g, n, stream, fuse_border); return; }
+#define X(DD, PP) if (g.D == DD && np == PP) { launch_one<DD, PP>(Lp, Rp, disp, cost, g, n, stream, fuse_border, strips_hint); return; }
     RTDM_FAST_TABLE(X)
 #undef X
 }

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 using namespace rtdm;
@@ -52,6 +53,7 @@ struct rtdm_bm {
     uint8_t *dLp, *dRp;            // prefiltered planes   [maxB][maxH][ppitch]
     uint8_t *dInL, *dInR;          // staging for the host entry points
     int16_t* dOut;                 //                      [maxB][maxH][maxW]
+    std::vector<std::pair<unsigned long long, int>> tuned;   // measured strip counts per (geometry, batch) shape
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
     int16_t* dHead;
@@ -280,6 +282,49 @@ static void stage_end(rtdm_bm* bm, hipStream_t s, StageEvent* ev)
 
 static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s);
 
+// Row strips per frame for the fast search of a batch, chosen by measurement the first time a (geometry, batch) shape is
+// seen and remembered in the handle: the model (fast_strips_model) is right on average, but neighbouring strip counts
+// differ by up to 5 % through scheduling effects it cannot see (profiles/r01_xcd_mapping_sweep.txt).  The search only
+// writes its own outputs, so timing it a few times on the caller's data is harmless.  Small batches (the reference
+// changes the ROI every frame) keep the model.  RTDM_AUTOTUNE=0 switches this off.
+static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plane16W disp, const BMGeom& g, int n, hipStream_t s, bool fuse)
+{
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("RTDM_AUTOTUNE"); enabled = e ? atoi(e) : 1; }
+    if (!enabled || n < 16 || getenv("RTDM_FAST_WGS")) return 0;
+    const unsigned long long key = ((unsigned long long)g.W << 48) ^ ((unsigned long long)g.H << 36) ^ ((unsigned long long)n << 24) ^
+                                   ((unsigned long long)g.cx0 << 12) ^ (unsigned long long)g.cx1 ^ ((unsigned long long)g.vy0 << 20) ^
+                                   ((unsigned long long)g.vy1 << 8) ^ ((unsigned long long)fuse << 63);
+    for (const auto& t : bm->tuned) if (t.first == key) return t.second;
+    const int model = fast_strips_model(g, n), cap = (g.vy1 - g.vy0 + 15) / 16;
+    int best = model;
+    float best_ms = 1e30f;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
+    static const float f[] = {0.7f, 0.85f, 1.0f, 1.15f, 1.3f, 1.5f};
+    int seen[6], nseen = 0;
+    for (float fk : f) {
+        const int c = std::max(1, std::min(cap, (int)(model * fk + 0.5f)));
+        bool dup = false;
+        for (int i = 0; i < nseen; ++i) dup |= seen[i] == c;
+        if (dup) continue;
+        seen[nseen++] = c;
+        launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);          // warm
+        float ms = 1e30f;
+        for (int rep = 0; rep < 2; ++rep) {
+            (void)hipEventRecord(a, s);
+            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);
+            (void)hipEventRecord(b, s);
+            float t = 0.f;
+            if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&t, a, b) == hipSuccess) ms = std::min(ms, t);
+        }
+        if (ms < best_ms) { best_ms = ms; best = c; }
+    }
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    bm->tuned.push_back(std::make_pair(key, best));
+    return best;
+}
+
 // One chunk (n <= maxB) of device-resident frames, enqueued on `s`.  The row kernels move 8 columns per 128-bit
 // access and let a ragged last chunk spill into the row padding, so they need 16-byte aligned rows of at least
 // W rounded up to 8 elements whose padding is ours to write.  A caller's plane qualifies only if W % 8 == 0 and it
@@ -327,7 +372,7 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
             fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
             static const bool separate = getenv("RTDM_SEPARATE_BORDER") != nullptr;   // A/B switch
             const bool fuse = border_search_supported(g) && !separate;
-            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse);
+            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse));
             if (fuse) {
             } else if (border_search_supported(g)) {
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, s, lx0, lx1, rx0, rx1);

@@ -50,8 +50,10 @@ void launch_search_generic(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, cons
 // remaining border columns [lx0,lx1) and [rx0,rx1) go to the generic kernel.
 bool fast_search_supported(const BMGeom& g);
 // fuse_border: the border columns are searched by extra workgroups of the same launch.
+// strips_hint > 0: row strips per frame to use (a measured choice); 0: fast_strips_model(g, n).
 void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g,
-                        int n, hipStream_t stream, bool fuse_border);
+                        int n, hipStream_t stream, bool fuse_border, int strips_hint = 0);
+int fast_strips_model(const BMGeom& g, int n);
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
 // wave-per-column kernel for those border columns (falls back to the generic kernel if unsupported)
 bool border_search_supported(const BMGeom& g);
