@@ -24,16 +24,25 @@ bool border_search_supported(const BMGeom& g)
 }
 
 // Geometry + LDS bytes of the border work; returns the grid (x = column groups, y = strips), 0 columns -> false.
-bool border_geometry(const BMGeom& g, int lx0, int lx1, int rx0, int rx1, BorderGeom* out, int* gx, int* gy, size_t* lds_bytes)
+// Rows per border workgroup: 128 for batches (the w-1 halo rows are then 6 % of the visits), shorter when the whole launch
+// would otherwise consist of a handful of long, latency-bound walks (single frames: the reference's real-time case).
+static int border_rows(int nrows, int ncols, int n)
+{
+    static int rs_env = -1;
+    if (rs_env < 0) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 0; }
+    if (rs_env >= 8) return rs_env;
+    const long want = (long)nrows * ((ncols + 3) / 4) * n / 256;     // rows per workgroup that still leave >= 256 workgroups
+    return (int)std::min(128L, std::max(16L, want));
+}
+
+bool border_geometry(const BMGeom& g, int lx0, int lx1, int rx0, int rx1, int n, BorderGeom* out, int* gx, int* gy, size_t* lds_bytes)
 {
     const int ncols = max(0, lx1 - lx0) + max(0, rx1 - rx0);
     if (ncols <= 0) return false;
     BorderGeom bg;
     bg.lx0 = lx0; bg.lx1 = max(lx1, lx0); bg.rx0 = rx0; bg.rx1 = max(rx1, rx0);
     const int nrows = g.vy1 - g.vy0;
-    static int rs_env = 0;
-    if (!rs_env) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 128; if (rs_env < 8) rs_env = 128; }
-    bg.rs = rs_env;
+    bg.rs = border_rows(nrows, ncols, n);
     bg.rsp = (g.D + g.w + 3 + 63 + 64) & ~3;       // + one chunk of slack for lanes with e >= D
     const int nch = (g.D + 63) / 64;
     const size_t per_wave = ((size_t)RB * bg.rsp + (size_t)RB * 32 + (size_t)g.w * (nch * 64) * 2 + (size_t)g.w * 4 + 15) & ~(size_t)15;
@@ -49,9 +58,7 @@ void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const
     BorderGeom bg;
     bg.lx0 = lx0; bg.lx1 = max(lx1, lx0); bg.rx0 = rx0; bg.rx1 = max(rx1, rx0);
     const int nrows = g.vy1 - g.vy0;
-    static int rs_env = 0;
-    if (!rs_env) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 128; if (rs_env < 8) rs_env = 128; }
-    bg.rs = rs_env;
+    bg.rs = border_rows(nrows, ncols, n);
     bg.rsp = (g.D + g.w + 3 + 63 + 64) & ~3;       // + one chunk of slack for lanes with e >= D
     const int nch = (g.D + 63) / 64;
     const size_t per_wave = ((size_t)RB * bg.rsp + (size_t)RB * 32 + (size_t)g.w * (nch * 64) * 2 + (size_t)g.w * 4 + 15) & ~(size_t)15;

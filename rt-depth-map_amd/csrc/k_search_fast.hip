@@ -382,7 +382,7 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     if (fuse_border) {
         int lx0, lx1, rx0, rx1; size_t blds = 0;
         fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
-        if (border_geometry(g, lx0, lx1, rx0, rx1, &bg, &fg.bgx, &fg.bgy, &blds)) ldsb = max(ldsb, blds);
+        if (border_geometry(g, lx0, lx1, rx0, rx1, n, &bg, &fg.bgx, &fg.bgy, &blds)) ldsb = max(ldsb, blds);
         else fg.bgx = fg.bgy = 0;
     }
     fg.nfast = (unsigned)tiles * strips * n; fg.nborder = (unsigned)(fg.bgx * fg.bgy) * n;

@@ -12,7 +12,7 @@ static constexpr int RB = 8;   // rows staged per batch
 struct BorderGeom { int lx0, lx1, rx0, rx1, rs, rsp; };
 
 // host side (k_search_border.hip): geometry, grid and LDS bytes of the border work; false if there is none
-bool border_geometry(const BMGeom& g, int lx0, int lx1, int rx0, int rx1, BorderGeom* out, int* gx, int* gy, size_t* lds_bytes);
+bool border_geometry(const BMGeom& g, int lx0, int lx1, int rx0, int rx1, int n, BorderGeom* out, int* gx, int* gy, size_t* lds_bytes);
 
 // Wave-wide unsigned minimum with DPP row operations (no LDS round trips); result is uniform.
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
