@@ -163,15 +163,18 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
         const int col = (isr ? Rbase : Lbase) + c + 4 * m;
         it_r[it] = isr; it_q[it] = col & ~3; it_sh[it] = col & 3; it_ok[it] = idx < SLOT;
     }
-    const int pitch_lim = (int)Lp.pitch;     // both prefiltered planes share pitch and allocation slack
+    // The loads are unconditional: bytes past a row's end only ever reach lanes that are not `active` (their windows lie
+    // outside the searched columns), and the prefiltered planes are allocated with 1 KB of slack behind the last row.
+    // (Per-lane load predicates would sit in SGPR pairs across the whole row loop; with this kernel's scalar pressure
+    // they were spilled to VGPR lanes and cost a v_readlane pair per load and row.)
     uint32_t pre[ITEMS][2];
     auto issue = [&](int row) {
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint8_t* rowp = (it_r[it] ? Rb : Lb) + (size_t)row * Lp.pitch;
             const int q = it_q[it];
-            pre[it][0] = (it_ok[it] && q + 4 <= pitch_lim) ? *(const uint32_t*)(rowp + q) : 0u;
-            pre[it][1] = (it_ok[it] && q + 8 <= pitch_lim) ? *(const uint32_t*)(rowp + q + 4) : 0u;
+            pre[it][0] = *(const uint32_t*)(rowp + q);
+            pre[it][1] = *(const uint32_t*)(rowp + q + 4);
         }
     };
     auto commit = [&](int slot) {

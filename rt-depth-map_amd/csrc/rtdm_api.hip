@@ -154,9 +154,9 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     // per-pixel workspace and the internal disparity plane use rows of Ws = max_width rounded up to 8 elements
     const size_t px = (size_t)((max_width + 7) & ~7) * max_height * max_batch;
     hipError_t e = hipStreamCreateWithFlags(&bm->stream, hipStreamNonBlocking);
-    // + slack: the border-column search stages whole dwords and may read a few bytes past a row's end
-    if (e == hipSuccess) e = hipMalloc((void**)&bm->dLp, plane + 256);
-    if (e == hipSuccess) e = hipMalloc((void**)&bm->dRp, plane + 256);
+    // + slack: the search kernels stage whole dwords of whole tiles and may read past the last row's end
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dLp, plane + 1024);
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dRp, plane + 1024);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dInL, plane);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dInR, plane);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dOut, px * sizeof(int16_t));
