@@ -133,6 +133,26 @@ def test_device_tensors_of_every_alignment_class(pkg, oracle, synth, W, H):
         assert np.array_equal(got[i], oracle.bm_compute(L[i], R[i], numDisparities=D, blockSize=w, nthreads=8)), (W, H, i)
 
 
+def test_batches_large_enough_to_be_autotuned(pkg, oracle, synth):
+    # batches of >= 16 frames time several row-strip counts on the first call (rtdm_api.hip, tune_strips); whatever is
+    # chosen, every frame must still be the oracle's, on the tuning call and on the calls after it
+    import torch
+    n, W, H, D, w = 24, 400, 150, 64, 9
+    L, R = synth.make_stream(4242, n, W, H, D)
+    dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n)
+    outs = []
+    for _ in range(3):
+        dD = torch.full((n, H, W), 12345, dtype=torch.int16, device="cuda")
+        m.compute_device(dL, dR, dD, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        outs.append(dD.cpu().numpy())
+    m.close()
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    for i in (0, 7, 23):
+        assert np.array_equal(outs[0][i], oracle.bm_compute(L[i], R[i], numDisparities=D, blockSize=w, nthreads=8)), i
+
+
 def test_too_wide_is_refused_not_crashed(pkg):
     with pytest.raises(pkg.binding.RtdmError) as e:
         pkg.HIPMatcher(numOfDisparities=64, blockSize=9, width=4097, height=32)
