@@ -575,6 +575,13 @@ template <int RS>
 __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int Ws, int H,
                                                          int y_lo, int npairs, int newVal, int maxDiff)
 {
+    // contacts found by the 256 threads are queued in LDS and united afterwards by the first threads, one union per
+    // lane: a union is a chain of dependent global accesses, and a wave with a single busy lane stalls as long as a full one
+    constexpr int QCAP = 1024;
+    __shared__ int2 queue[QCAP];
+    __shared__ int qn;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
     const int nxb = (W + 7) >> 3;                         // a ragged last chunk reads the plane's padding columns and masks them
     const int nstrips = (npairs + RS - 1) / RS;
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -622,22 +629,29 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
             for (int k = 0; k < 8; ++k) {
                 const bool c = (cm >> k) & 1;
                 const int ha = ha8.v[k], hb = hb8.v[k];
-                if (c && !(pc && ph0 == ha && ph1 == hb)) uf_union(label, base + ha, base + Ws + hb);
+                if (c && !(pc && ph0 == ha && ph1 == hb)) {
+                    const int slot = atomicAdd(&qn, 1);
+                    if (slot < QCAP) queue[slot] = make_int2(base + ha, base + Ws + hb);
+                    else uf_union(label, base + ha, base + Ws + hb);
+                }
                 pc = c; ph0 = ha; ph1 = hb;
             }
         }
         a8 = b8; ha8 = hb8; ha_loaded = cm != 0;
         d += disp.pitch_e; h += Ws; base += Ws;
     }
+    __syncthreads();
+    const int total = min(qn, QCAP);
+    for (int i = threadIdx.x; i < total; i += 256) uf_union(label, queue[i].x, queue[i].y);
 }
 
 __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, const uint32_t* runs,
                                                    const int32_t* rowcnt, int Ws, int nrows, int maxSize)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);        // one wave per row of the batch
-    if (row >= nrows) return;
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);        // half a wave per row of the batch: rows have a few dozen runs
+    if (row >= nrows) return;                                   // and every lane's work is a chain of dependent loads
     const int cnt = rowcnt[row], base = row * Ws;
-    for (int i = threadIdx.x & 63; i < cnt; i += 64) {
+    for (int i = threadIdx.x & 31; i < cnt; i += 32) {
         const uint32_t rn = runs[base + i];
         const int idx = base + (int)(rn & 0xffffu), len = (int)(rn >> 16);
         const int root = uf_find(label, idx);
@@ -651,12 +665,12 @@ __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t*
                                                    const uint32_t* runs, const int32_t* rowcnt, int Ws, int H, int nrows,
                                                    int newVal, int maxSize)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);        // half a wave per row, as in k_spk_count
     if (row >= nrows) return;
     const int cnt = rowcnt[row], base = row * Ws;
     const int f = row / H, y = row - f * H;
     int16_t* drow = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    for (int i = threadIdx.x & 63; i < cnt; i += 64) {
+    for (int i = threadIdx.x & 31; i < cnt; i += 32) {
         const uint32_t rn = runs[base + i];
         const int x = (int)(rn & 0xffffu), len = (int)(rn >> 16);
         // after k_spk_count a head is at most a couple of hops from its root (a late path-halving
@@ -703,8 +717,8 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
     }
     const int nrows = n * H;
-    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 3) / 4), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
-    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 3) / 4), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
+    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 7) / 8), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
+    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 7) / 8), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
 }
 
 }  // namespace rtdm
