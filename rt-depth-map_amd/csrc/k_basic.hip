@@ -648,10 +648,10 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
 __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, const uint32_t* runs,
                                                    const int32_t* rowcnt, int Ws, int nrows, int maxSize)
 {
-    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);        // half a wave per row of the batch: rows have a few dozen runs
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);        // 16 lanes per row of the batch: rows have a few dozen runs
     if (row >= nrows) return;                                   // and every lane's work is a chain of dependent loads
     const int cnt = rowcnt[row], base = row * Ws;
-    for (int i = threadIdx.x & 31; i < cnt; i += 32) {
+    for (int i = threadIdx.x & 15; i < cnt; i += 16) {
         const uint32_t rn = runs[base + i];
         const int idx = base + (int)(rn & 0xffffu), len = (int)(rn >> 16);
         const int root = uf_find(label, idx);
@@ -665,12 +665,12 @@ __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t*
                                                    const uint32_t* runs, const int32_t* rowcnt, int Ws, int H, int nrows,
                                                    int newVal, int maxSize)
 {
-    const int row = blockIdx.x * 8 + (threadIdx.x >> 5);        // half a wave per row, as in k_spk_count
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);        // 16 lanes per row, as in k_spk_count
     if (row >= nrows) return;
     const int cnt = rowcnt[row], base = row * Ws;
     const int f = row / H, y = row - f * H;
     int16_t* drow = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    for (int i = threadIdx.x & 31; i < cnt; i += 32) {
+    for (int i = threadIdx.x & 15; i < cnt; i += 16) {
         const uint32_t rn = runs[base + i];
         const int x = (int)(rn & 0xffffu), len = (int)(rn >> 16);
         // after k_spk_count a head is at most a couple of hops from its root (a late path-halving
@@ -717,8 +717,8 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
     }
     const int nrows = n * H;
-    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 7) / 8), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
-    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 7) / 8), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
+    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 15) / 16), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
+    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 15) / 16), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
 }
 
 }  // namespace rtdm
