@@ -438,7 +438,11 @@ int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint
     // two lanes: the caller's stream fans out to the lane streams and joins them again
     HIPC(hipEventRecord(bm->evIn, s));
     for (int k = 0; k < 2; ++k) HIPC(hipStreamWaitEvent(bm->lane[k].stream, bm->evIn, 0));
-    const int piece = std::min(bm->laneB, (n + 1) / 2);
+    // pieces alternate between the lanes; more than two make the lanes drift out of phase, so that one lane's row kernels
+    // (memory / latency bound) run under the other lane's search (VALU bound).  RTDM_PIECES = pieces per call.
+    static int npieces = 0;
+    if (!npieces) { const char* e = getenv("RTDM_PIECES"); npieces = e ? atoi(e) : 2; if (npieces < 2) npieces = 2; }
+    const int piece = std::max(1, std::min(bm->laneB, (n + npieces - 1) / npieces));
     int k = 0;
     for (int i0 = 0; i0 < n; i0 += piece, k ^= 1) {
         const int m = std::min(piece, n - i0);
