@@ -242,7 +242,13 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
             slot_out = (slot_out + 1 == RING) ? 0 : slot_out + 1;
         }
 
-        if (s >= w - 1) {
+        // Selection is skipped for a wave none of whose 64 columns can produce a disparity here: untextured (flat walls,
+        // sky: the texture test fails before anything else is looked at), outside the tile, or masked.  Exact: such a
+        // pixel is FILTERED and writes no cost whatever its SADs are.
+        const bool dead = !active || masked_col || (int)tsum < g.tex;
+        if (s >= w - 1 && __builtin_amdgcn_ballot_w64(!dead) == 0) {
+            if (active) db[(size_t)(row_in - r) * disp.pitch_e + col] = (int16_t)g.filtered;
+        } else if (s >= w - 1) {
             const int y = row_in - r;
             uint32_t rr[NR];
 #pragma unroll
