@@ -301,8 +301,8 @@ static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plan
     float best_ms = 1e30f;
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
-    static const float f[] = {0.7f, 0.85f, 1.0f, 1.15f, 1.3f, 1.5f};
-    int seen[6], nseen = 0;
+    static const float f[] = {0.6f, 0.7f, 0.8f, 0.9f, 1.0f, 1.1f, 1.2f, 1.35f, 1.5f, 1.75f};
+    int seen[10], nseen = 0;
     for (float fk : f) {
         const int c = std::max(1, std::min(cap, (int)(model * fk + 0.5f)));
         bool dup = false;
