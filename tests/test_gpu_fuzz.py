@@ -153,6 +153,30 @@ def test_batches_large_enough_to_be_autotuned(pkg, oracle, synth):
         assert np.array_equal(outs[0][i], oracle.bm_compute(L[i], R[i], numDisparities=D, blockSize=w, nthreads=8)), i
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_morphology_shapes(pkg, oracle, seed):
+    # the filter works on 64x32 tiles with a 20/16 halo and four-pixel groups: sizes below, at and across those
+    # granularities, blobby masks (what the HSV threshold delivers) and arbitrary gray images, aligned and odd pitches
+    import torch
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(500 + seed)
+    W = int(rng.choice([1, 3, 4, 17, 63, 64, 65, 100, 128, 131, 200, 256, 257, 300]))
+    H = int(rng.choice([1, 2, 9, 31, 32, 33, 50, 64, 70, 99]))
+    field = ndi.uniform_filter(rng.random((3, H, W)), (0, min(9, H), min(9, W)))
+    imgs = np.stack([(field[0] > np.median(field[0])).astype(np.uint8) * 255,
+                     rng.integers(0, 256, (H, W), dtype=np.uint8),
+                     (field[2] * 255).astype(np.uint8)])
+    mf = pkg.HIPMorphologicalFilter(W, H, 8, max_batch=2)
+    d_in = torch.from_numpy(imgs).cuda(); d_out = torch.empty_like(d_in)
+    mf.run_device(d_in, d_out, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for i in range(3):
+        assert np.array_equal(got[i], oracle.morph_open_close(imgs[i])), (seed, W, H, i)
+    assert np.array_equal(mf.run(imgs[1]), got[1])              # host path = device path
+    mf.close()
+
+
 def test_too_wide_is_refused_not_crashed(pkg):
     with pytest.raises(pkg.binding.RtdmError) as e:
         pkg.HIPMatcher(numOfDisparities=64, blockSize=9, width=4097, height=32)
