@@ -316,15 +316,33 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
     for (int x = threadIdx.x; x < W; x += 256) { key[x] = ~0ull; bdv[x] = (int16_t)(minD - 1); row[x] = (int16_t)INV; }
     __syncthreads();
     const uint16_t* srow = S + (((size_t)f * g.H + y) * g.W1) * D;
-    for (int xi = wv; xi < g.W1; xi += 4) {
-        const uint16_t* s = srow + (size_t)xi * D;
+    // the wave's pixels are a serial chain (reduce, test, vote): their S values are fetched PF pixels ahead, otherwise every
+    // pixel would cost a full memory round trip
+    constexpr int PF = 6;
+    uint16_t pre[PF][NCH];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+        const int xp = wv + 4 * p;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { const int d = lane + 64 * c; pre[p][c] = (xp < g.W1 && d < D) ? srow[(size_t)xp * D + d] : (uint16_t)0x7fff; }
+    }
+    for (int xb = wv; xb < g.W1; xb += 4 * PF) {
+#pragma unroll
+      for (int p = 0; p < PF; ++p) {
+        const int xi = xb + 4 * p;
+        if (xi >= g.W1) break;
         int v[NCH];
         unsigned k = 0x7fffffffu;                            // (reduced as signed: keep the sentinel positive)
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int d = lane + 64 * c;
-            v[c] = d < D ? (int)s[d] : 0x7fff;
+            v[c] = d < D ? (int)pre[p][c] : 0x7fff;
             if (d < D) k = min(k, ((unsigned)v[c] << 8) | (unsigned)d);
+        }
+        {
+            const int xn = xi + 4 * PF;                      // refill this ring slot
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) { const int d = lane + 64 * c; if (xn < g.W1 && d < D) pre[p][c] = srow[(size_t)xn * D + d]; }
         }
         k = (unsigned)wave_min_i32((int)k);                  // keys are < 2^24: signed min is fine
         const int mins = (int)(k >> 8), bd = (int)(k & 0xffu);
@@ -351,10 +369,11 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
             int d16 = bd * 16;
             if (bd > 0 && bd < D - 1) {
                 const int den = max(sn + sp - 2 * mins, 1);
-                d16 += ((sn - sp) * 16 + den) / (den * 2);
+                d16 += div_trunc_rcp((sn - sp) * 16 + den, den * 2);        // |numerator| < 2^21
             }
             row[x] = (int16_t)(d16 + minD * 16);
         }
+      }
     }
     __syncthreads();
     int16_t* out = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;

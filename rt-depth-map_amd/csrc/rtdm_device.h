@@ -46,6 +46,19 @@ __device__ __forceinline__ void row_scan(int* v, int W, int* wsum)
     __syncthreads();
 }
 
+// truncating num / den for den > 0, |num| < 2^24, without the ~30-instruction integer division sequence
+__device__ __forceinline__ int div_trunc_rcp(int num, int den)
+{
+    const unsigned an = (unsigned)(num < 0 ? -num : num);
+    unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
+    int rem = (int)an - (int)(q * (unsigned)den);
+    if (rem < 0) { --q; rem += den; }
+    if (rem < 0) { --q; rem += den; }
+    if (rem >= den) { ++q; rem -= den; }
+    if (rem >= den) { ++q; }
+    return num < 0 ? -(int)q : (int)q;
+}
+
 __device__ __forceinline__ bool conn(int a, int b, int newVal, int maxDiff)
 { return a != newVal && b != newVal && abs(a - b) <= maxDiff; }
 
