@@ -70,3 +70,13 @@ def test_product_package_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or f == "Makefile":
                 text = open(os.path.join(dp, f), errors="ignore").read()
                 assert "rtdm_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_header_is_plain_c_and_cpp():
+    # the boundary is a C ABI: the header must compile as C99 (what cgo / a C caller sees) and as C++11 (the
+    # reference's own dialect, Makefile.build: -std=c++11) without warnings
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "rtdm.h")
+    for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", lang, hdr], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
