@@ -80,3 +80,38 @@ def test_header_is_plain_c_and_cpp():
     for cc, std, lang in (("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")):
         r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", lang, hdr], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def _build_c_caller(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_caller")
+    libdir = os.path.join(ROOT, "rt-depth-map_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_caller.c"), "-L", libdir, "-lrtdm_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    return exe
+
+
+def test_plain_c_program_links_and_fails_loudly_without_a_device(tmp_path):
+    import subprocess
+    import torch
+    out = subprocess.run([_build_c_caller(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    if not torch.cuda.is_available():
+        assert "create: -3" in out.stdout
+
+
+@pytest.mark.gpu
+def test_plain_c_program_matches_the_oracle(tmp_path):
+    import subprocess
+    import numpy as np
+    from oracle import oracle as orc
+    orc.build()
+    synth = load("synth")
+    W, H, D, w = 320, 200, 32, 7
+    L, R = synth.make_pair(synth.STREAM_SEED + 77, W, H, D)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    src.write_bytes(L.tobytes() + R.tobytes())
+    rc = subprocess.run([_build_c_caller(tmp_path), str(src), str(dst), str(W), str(H), str(D), str(w)], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stdout + rc.stderr
+    got = np.frombuffer(dst.read_bytes(), np.int16).reshape(H, W)
+    assert np.array_equal(got, orc.bm_compute(L, R, numDisparities=D, blockSize=w, nthreads=8))
