@@ -177,6 +177,29 @@ def test_random_morphology_shapes(pkg, oracle, seed):
     mf.close()
 
 
+def test_large_batch_every_position_is_served(pkg, oracle, synth):
+    # the search kernel decodes (tile, strip, frame) from a 1-D workgroup id: frames at the start, in the middle and at
+    # the end of a batch of 96, and the frames of a second call with a different batch size on the same handle
+    import torch
+    n, W, H, D, w = 96, 640, 360, 64, 9
+    L, R = synth.make_stream(999, n, W, H, D)
+    dL, dR = torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda()
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n)
+    st = torch.cuda.current_stream().cuda_stream
+    m.compute_device(dL, dR, dD, st)
+    torch.cuda.synchronize()
+    got = dD.cpu().numpy()
+    want = {i: oracle.bm_compute(L[i], R[i], numDisparities=D, blockSize=w, nthreads=8) for i in (0, 1, 37, 94, 95)}
+    for i, wnt in want.items():
+        assert np.array_equal(got[i], wnt), i
+    dD2 = torch.empty((40, H, W), dtype=torch.int16, device="cuda")
+    m.compute_device(dL[50:90].contiguous(), dR[50:90].contiguous(), dD2, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dD2, dD[50:90])
+    m.close()
+
+
 def test_too_wide_is_refused_not_crashed(pkg):
     with pytest.raises(pkg.binding.RtdmError) as e:
         pkg.HIPMatcher(numOfDisparities=64, blockSize=9, width=4097, height=32)
