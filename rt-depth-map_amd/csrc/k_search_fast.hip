@@ -29,6 +29,8 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
 { return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); }
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
 __device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
 { return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
 __device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b)
@@ -253,42 +255,66 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
             uint32_t rr[NR];
 #pragma unroll
             for (int i = 0; i < NG; ++i) { rr[2 * i] = (uint32_t)S[i]; rr[2 * i + 1] = (uint32_t)(S[i] >> 32); }
-            // (minsad, first argmin) via 32-bit keys sad << 8 | e
+            // (minsad, FIRST argmin) in two levels.  Level 1: packed minima of groups of four registers (eight
+            // disparities): v_pk_min_u16 serves two values per instruction and needs no key.  Level 2: keys
+            // min << 8 | group over the 2 NGp half-group minima -> (minsad, first group that holds it).  Level 3: the six
+            // registers around that group are fetched (they also hold sad[a-1] and sad[a+1]) and the eight in-group
+            // keys sad << 8 | e give the first e.  Ties: the smallest e lies in the smallest group that attains the
+            // minimum, and level 3 takes the smallest e inside it.
+            constexpr int NGp = NR / 4;
             uint32_t kacc[2] = {0xffffffffu, 0xffffffffu};   // two chains: no back-to-back dependency
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                const uint32_t ec = (uint32_t)(2 * i) | ((uint32_t)(2 * i + 1) << 8);
-                const uint32_t klo = __builtin_amdgcn_perm(rr[i], ec, 0x0C050400u);
-                const uint32_t khi = __builtin_amdgcn_perm(rr[i], ec, 0x0C070601u);
-                kacc[i & 1] = min(min(kacc[i & 1], klo), khi);
+            for (int gq = 0; gq < NGp; ++gq) {
+                const uint32_t gm = pk_min(pk_min(rr[4 * gq], rr[4 * gq + 1]), pk_min(rr[4 * gq + 2], rr[4 * gq + 3]));
+                const uint32_t gc = (uint32_t)gq | ((uint32_t)gq << 8);
+                const uint32_t klo = __builtin_amdgcn_perm(gm, gc, 0x0C050400u);
+                const uint32_t khi = __builtin_amdgcn_perm(gm, gc, 0x0C070601u);
+                kacc[gq & 1] = min(min(kacc[gq & 1], klo), khi);
             }
             const uint32_t kmin = min(kacc[0], kacc[1]);
             const int m1 = (int)(kmin >> 8);
-            const int a = (int)(kmin & 0xffu);
-            // fetch the two packed registers that hold sad[a-1 .. a+1]
-            const int am1 = a > 0 ? a - 1 : 0;
-            const int j = am1 >> 1;
-            uint32_t cur[NR + 1];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) cur[i] = rr[i];
-            cur[NR] = 0;
+            const int gs = (int)(kmin & 0xffu);
+            // six[k] = rr[4 gs - 1 + k], k = 0..5 (0 outside the array): binary select on the bits of gs
+            uint32_t six[6];
             {
-                constexpr int HB = (NR - 1) >= 64 ? 64 : (NR - 1) >= 32 ? 32 : (NR - 1) >= 16 ? 16 : (NR - 1) >= 8 ? 8 : 4;
-                int len = NR + 1;
+                uint32_t cand[6][NGp];
 #pragma unroll
-                for (int bit = HB; bit >= 1; bit >>= 1) {
-                    const bool up = (j & bit) != 0;
+                for (int k = 0; k < 6; ++k)
 #pragma unroll
-                    for (int i = 0; i < bit + 1; ++i) {
-                        if (i < len) {
-                            const uint32_t hi = (i + bit < len) ? cur[i + bit] : 0u;
-                            cur[i] = up ? hi : cur[i];
-                        }
+                    for (int gq = 0; gq < NGp; ++gq) {
+                        const int idx = 4 * gq - 1 + k;
+                        cand[k][gq] = (idx >= 0 && idx < NR) ? rr[idx] : 0u;
                     }
-                    len = (bit + 1 < len) ? bit + 1 : len;
+                constexpr int HBG = (NGp - 1) >= 16 ? 16 : (NGp - 1) >= 8 ? 8 : (NGp - 1) >= 4 ? 4 : (NGp - 1) >= 2 ? 2 : 1;
+                int len = NGp;
+#pragma unroll
+                for (int bit = HBG; bit >= 1; bit >>= 1) {
+                    const bool up = (gs & bit) != 0;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k)
+#pragma unroll
+                        for (int i = 0; i < bit; ++i)
+                            if (i < len) cand[k][i] = up ? ((i + bit < len) ? cand[k][i + bit] : 0u) : cand[k][i];
+                    len = bit < len ? bit : len;
                 }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) six[k] = cand[k][0];
             }
-            const uint32_t e0 = cur[0], e1 = cur[1];
+            uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
+                const uint32_t klo = __builtin_amdgcn_perm(six[1 + q], ec, 0x0C050400u);
+                const uint32_t khi = __builtin_amdgcn_perm(six[1 + q], ec, 0x0C070601u);
+                k3[q & 1] = min(min(k3[q & 1], klo), khi);
+            }
+            const int a = 8 * gs + (int)(min(k3[0], k3[1]) & 0xffu);
+            // the two packed registers that hold sad[a-1 .. a+1] are among the six
+            const int am1 = a > 0 ? a - 1 : 0;
+            const int jl = (am1 >> 1) - (4 * gs - 1);                 // 0..4
+            const bool j1 = (jl & 1) != 0, j2 = (jl & 2) != 0, j4 = (jl & 4) != 0;
+            const uint32_t e0 = j4 ? six[4] : (j2 ? (j1 ? six[3] : six[2]) : (j1 ? six[1] : six[0]));
+            const uint32_t e1 = j4 ? six[5] : (j2 ? (j1 ? six[4] : six[3]) : (j1 ? six[2] : six[1]));
             const int posc = a > 0 ? (am1 & 1) + 1 : 0;         // position of sad[a] among the 4 fetched
             const auto elem = [&](int pos) -> int {
                 return (int)__builtin_amdgcn_perm(e1, e0, 0x0C0C0100u + 0x0202u * (uint32_t)pos);
