@@ -263,9 +263,11 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
             // minimum, and level 3 takes the smallest e inside it.
             constexpr int NGp = NR / 4;
             uint32_t kacc[2] = {0xffffffffu, 0xffffffffu};   // two chains: no back-to-back dependency
+            uint32_t gmin[NGp];                               // kept: the uniqueness test skips groups above its threshold
 #pragma unroll
             for (int gq = 0; gq < NGp; ++gq) {
                 const uint32_t gm = pk_min(pk_min(rr[4 * gq], rr[4 * gq + 1]), pk_min(rr[4 * gq + 2], rr[4 * gq + 3]));
+                gmin[gq] = gm;
                 const uint32_t gc = (uint32_t)gq | ((uint32_t)gq << 8);
                 const uint32_t klo = __builtin_amdgcn_perm(gm, gc, 0x0C050400u);
                 const uint32_t khi = __builtin_amdgcn_perm(gm, gc, 0x0C070601u);
@@ -333,6 +335,8 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
                 uint32_t zz[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int i = 0; i < NR; i += 4) {
+                    // a group none of whose eight values reaches the threshold in any lane adds nothing (exact)
+                    if (__builtin_amdgcn_ballot_w64(pk_sub_sat(T1pk, gmin[i >> 2]) != 0u) == 0) continue;
                     uint32_t t0 = pk_sub_sat(T1pk, rr[i]), t1 = pk_sub_sat(T1pk, rr[i + 1]);
                     uint32_t t2 = pk_sub_sat(T1pk, rr[i + 2]), t3 = pk_sub_sat(T1pk, rr[i + 3]);
                     asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
