@@ -6,9 +6,10 @@
 // are masked in the end, but validateDisparity's first pass lets them vote, so they must be exact.
 // They are only 2*(w/2) columns, which suits the transposed mapping: one WAVE per border column,
 // LANES = reversed disparity index e (e = lane + 64*c), walking down a strip of rows.
-//   * per row the wave stages the (w-1+D)-byte right span and the w left samples in LDS (8 rows per
-//     batch so that global latency is paid once per batch), then SAD(e) = sum over the w samples
-//     with v_sad_u8 on zero-extended bytes;
+//   * per row the wave stages the (w-1+D)-byte right span (whole dwords) and the w left samples in LDS (8 rows
+//     per batch so that global latency is paid once per batch); lane e's w window bytes R[rb(dx)+e] are gathered
+//     from 8-byte spans by v_alignbyte + v_perm with wave-uniform selectors (they only depend on where the clamp
+//     bites), so SAD(e) is ceil(w/4) four-byte v_sad_u8;
 //   * vertical sliding window through an LDS ring of the last w row-SADs per e;
 //   * selection with wave-level operations: min-reduce of the key sad<<8|e (first minimum),
 //     __any() for the uniqueness test, readlane for sad[mind +- 1].

@@ -11,13 +11,18 @@
 //   * vertical: sliding window down the strip.  The entering row accumulates straight into the
 //     running sums (the quad-SAD's accumulator operand); the leaving row is recomputed from the
 //     LDS ring and subtracted with v_pk_sub_u16.
-//   * selection per output pixel, all in registers: 32-bit keys (sad << 8 | e) built by v_perm and
-//     reduced with v_min3_u32 give (minsad, FIRST argmin); uniqueness is the identity
+//   * selection per output pixel, all in registers and in two levels: packed minima of groups of eight
+//     disparities (v_pk_min_u16), 32-bit keys (min << 8 | group) built by v_perm and reduced with v_min3_u32
+//     give (minsad, first group), the six registers around that group come out of a v_cndmask tree and the
+//     eight in-group keys (sad << 8 | e) give the FIRST argmin; uniqueness is the identity
 //       sum_e max(T+1 - sad[e], 0)  ==  the same sum over {mind-1, mind, mind+1}
-//     evaluated with saturating packed u16 ops; sad[mind +- 1] come out of a 5-level v_cndmask tree.
+//     evaluated with saturating packed u16 ops (groups above the threshold in the whole wave are skipped);
+//     sad[mind +- 1] are among the six fetched registers.
+//   * launch: 1-D grid, XCD-aware (see FastGeom); row strips per frame from a cost model, measured once per
+//     batch shape by the caller (rtdm_api.hip, tune_strips).
 //   Only columns whose whole window is free of border clamping are handled here; the 2*(w/2)
-//   border columns go to the generic kernel (they are outside the valid rectangle but feed the
-//   left-right check).  Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
+//   border columns are searched by extra workgroups of the same grid (rtdm_border.h; they are outside the
+//   valid rectangle but feed the left-right check).  Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
 #include "rtdm_border.h"
 
 #include <cmath>
