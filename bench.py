@@ -185,10 +185,17 @@ def main():
     # HBM bytes of the dominant kernel from the rocprofv3 PMC passes (tools/pmc_traffic.sh; FETCH_SIZE x2 +
     # WRITE_SIZE, per the gfx950 correction); collected offline because --pmc cannot run inside this process
     traffic = None
+    compute_view = None
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if m.search_variant == "fast_qsad":
-            traffic = int(pm["kernels"]["k_search_fast<64,3>"]["hbm_bytes_per_pair"] * frames_per_launch)
+            k = pm["kernels"]["k_search_fast<64,3>"]
+            traffic = int(k["hbm_bytes_per_pair"] * frames_per_launch)
+            # the kernel is integer-VALU bound, not HBM bound: what the SQ counters of the same
+            # offline rocprofv3 run say about it
+            compute_view = {"bound": "valu", "valu_busy_frac_of_simd_cycles": k.get("valu_busy_frac_of_simd_cycles"),
+                            "valu_insts_per_pixel": k.get("valu_insts_per_pixel"), "wave_cycle_split": k.get("wave_cycle_split"),
+                            "source": "rocprofv3 --pmc SQ_* pass, profiles/r01_pmc_traffic.json"}
     except Exception:
         traffic = None
     out = {
@@ -208,6 +215,7 @@ def main():
                      "avg_launch_ms": round(avg_ms, 4), "pairs_per_launch": frames_per_launch,
                      "algorithmic_bytes_per_pair": ALGO_BYTES_PER_PAIR},
         "stage_ms_per_launch": {k: round(v["total_ms"] / max(1, v["launches"]), 4) for k, v in stages.items()},
+        "compute_view": compute_view,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg)
