@@ -139,6 +139,14 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    # a checkout without built libraries: build them (what __graft_entry__.build() does) -- rank 0 only, the others wait.
+    # This is building the product, not falling back: without the HIP library nothing below can run.
+    if not os.path.exists(os.path.join(ROOT, "rt-depth-map_amd", "lib", "librtdm_hip.so")):
+        if rank == 0:
+            import subprocess
+            subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "rt-depth-map_amd")])
+        if dist is not None:
+            dist.barrier()
     pkg = importlib.import_module("rt-depth-map_amd")
     if args.rccl_stream:
         return rccl_stream(args, pkg, torch, dist, rank, local_rank, world)
