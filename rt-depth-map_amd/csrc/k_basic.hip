@@ -373,7 +373,9 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
             const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
             bool bad0 = false, bad1 = false;
             if ((unsigned)xa < (unsigned)W) { const uint32_t q = key[xa]; if (q != ~0u) bad0 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
-            if ((unsigned)xb < (unsigned)W) { const uint32_t q = key[xb]; if (q != ~0u) bad1 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
+            // a pixel dies only if BOTH matches disagree: the second look-up is needed by the lanes whose first one did
+            // (consistent regions: none of the wave's lanes)
+            if (bad0 && (unsigned)xb < (unsigned)W) { const uint32_t q = key[xb]; if (q != ~0u) bad1 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
             kill |= (unsigned)(bad0 && bad1) << k;
         }
         if (kill) {
