@@ -34,6 +34,8 @@ struct StageEvent { hipEvent_t a, b; int stage; int frames; };
 struct Lane {
     hipStream_t stream;
     hipEvent_t done;
+    hipStream_t side;              // the border-column search runs here, next to the tile search (RTDM_BORDER_ASYNC)
+    hipEvent_t fork, join;
     uint8_t *dLp, *dRp;
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
@@ -186,6 +188,9 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
             const size_t po = fo * ((max_width + 7) & ~7) * max_height;     // in workspace pixels
             HIPC(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
             HIPC(hipEventCreateWithFlags(&ln.done, hipEventDisableTiming));
+            HIPC(hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
+            HIPC(hipEventCreateWithFlags(&ln.fork, hipEventDisableTiming));
+            HIPC(hipEventCreateWithFlags(&ln.join, hipEventDisableTiming));
             ln.dLp = bm->dLp + fo * bm->ppitch * max_height; ln.dRp = bm->dRp + fo * bm->ppitch * max_height;
             ln.dCost = bm->dCost + po; ln.dLabel = bm->dLabel + po; ln.dSize = bm->dSize + po;
             ln.dRuns = bm->dRuns + po; ln.dHead = bm->dHead + po; ln.dOut = bm->dOut + po; ln.dRowCnt = bm->dRowCnt + fo * max_height;
@@ -203,6 +208,9 @@ void rtdm_bm_destroy(rtdm_bm* bm)
     for (int k = 0; k < bm->nlanes; ++k) {
         if (bm->lane[k].stream) { (void)hipStreamSynchronize(bm->lane[k].stream); (void)hipStreamDestroy(bm->lane[k].stream); }
         if (bm->lane[k].done) (void)hipEventDestroy(bm->lane[k].done);
+        if (bm->lane[k].side) { (void)hipStreamSynchronize(bm->lane[k].side); (void)hipStreamDestroy(bm->lane[k].side); }
+        if (bm->lane[k].fork) (void)hipEventDestroy(bm->lane[k].fork);
+        if (bm->lane[k].join) (void)hipEventDestroy(bm->lane[k].join);
     }
     if (bm->evIn) (void)hipEventDestroy(bm->evIn);
     for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -371,9 +379,23 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
             int lx0, lx1, rx0, rx1;
             fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
             static const bool separate = getenv("RTDM_SEPARATE_BORDER") != nullptr;   // A/B switch
-            const bool fuse = border_search_supported(g) && !separate;
+            // Batches: the border columns run as a kernel of their own on a side stream, concurrently with the tile kernel.
+            // Its waves need 37-72 VGPRs and fit NEXT to the four tile waves of a SIMD, whereas inside the tile kernel's
+            // grid a border workgroup takes a tile workgroup's slot for the length of its latency-bound walk
+            // (search -2 %).  Single frames keep the fused launch (one kernel less).  RTDM_BORDER_ASYNC=0: always fused.
+            static const bool async_border = [] { const char* e = getenv("RTDM_BORDER_ASYNC"); return !e || atoi(e) != 0; }();
+            const bool side = async_border && border_search_supported(g) && n >= 16;
+            const bool fuse = border_search_supported(g) && !separate && !side;
+            if (side) {
+                HIPC(hipEventRecord(ln.fork, s));
+                HIPC(hipStreamWaitEvent(ln.side, ln.fork, 0));
+                launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, ln.side, lx0, lx1, rx0, rx1);
+                HIPC(hipEventRecord(ln.join, ln.side));
+            }
             launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse));
-            if (fuse) {
+            if (side) {
+                HIPC(hipStreamWaitEvent(s, ln.join, 0));
+            } else if (fuse) {
             } else if (border_search_supported(g)) {
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, s, lx0, lx1, rx0, rx1);
             } else {
