@@ -198,7 +198,8 @@ def main():
         pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         if m.search_variant == "fast_qsad":
             k = pm["kernels"]["k_search_fast<64,3>"]
-            traffic = int(k["hbm_bytes_per_pair"] * frames_per_launch)
+            kb = pm["kernels"].get("k_search_border<1>", {})               # runs beside the tile kernel on a side stream
+            traffic = int((k["hbm_bytes_per_pair"] + kb.get("hbm_bytes_per_pair", 0)) * frames_per_launch)
             # the kernel is integer-VALU bound, not HBM bound: what the SQ counters of the same
             # offline rocprofv3 run say about it
             compute_view = {"bound": "valu", "valu_busy_frac_of_simd_cycles": k.get("valu_busy_frac_of_simd_cycles"),
