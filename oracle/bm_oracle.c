@@ -90,6 +90,9 @@ int orc_bm_valid_rect(const orc_bm_params* p, int W, int H, int rect[4])
 }
 
 /* ---- A.3b SAD search ------------------------------------------------------------------ */
+static int g_legacy_right_clamp = 0;   /* rtdm_oracle.h, hazard H1 */
+void orc_bm_set_legacy_right_clamp(int on) { g_legacy_right_clamp = on != 0; }
+
 typedef struct {
     int W, H, D, minD, w, r, cap, tex, uniq, lofs, rofs, width1, nj;
     const uint8_t *Lp, *Rp;
@@ -135,7 +138,9 @@ void orc_bm_search(const orc_bm_params* p, const uint8_t* Lp, size_t lstep,
     for (int jj = 0; jj < c.nj; ++jj) {
         int j = jj - r;
         c.lcol[jj] = iclamp(c.lofs + j, 0, W - 1);
-        c.rbase[jj] = iclamp(c.rofs + j, 0, W - D);
+        /* 4.x: the last sample base keeps base + (D-1) inside the row.  3.x (legacy switch): base up to W-rofs-1, so
+         * rp[d] runs on into the following bytes (the next row when the step equals W).                              */
+        c.rbase[jj] = iclamp(c.rofs + j, 0, g_legacy_right_clamp ? W - c.rofs - 1 : W - D);
     }
     int32_t* V = (int32_t*)calloc((size_t)c.nj * D, sizeof(int32_t));
     int32_t* T = (int32_t*)calloc((size_t)c.nj, sizeof(int32_t));
@@ -305,7 +310,7 @@ int orc_bm_compute(const orc_bm_params* p, const uint8_t* L, size_t lstep,
         return ORC_OK;
     }
     uint8_t* Lp = (uint8_t*)malloc((size_t)W * H);
-    uint8_t* Rp = (uint8_t*)malloc((size_t)W * H);
+    uint8_t* Rp = (uint8_t*)calloc((size_t)W * H + (size_t)D, 1);   /* + D: the legacy clamp (H1) over-reads the last row */
     int32_t* cost = (int32_t*)malloc(sizeof(int32_t) * (size_t)W * H);
     orc_prefilter_xsobel(L, lstep, W, H, Lp, (size_t)W, p->preFilterCap);
     orc_prefilter_xsobel(R, rstep, W, H, Rp, (size_t)W, p->preFilterCap);

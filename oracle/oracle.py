@@ -35,6 +35,23 @@ def build(force=False):
     return _SO
 
 
+def build_native():
+    """bench.py's cpu_baseline leg: the same sources compiled -march=native ON THE BOX that runs them (the portable
+    build travels with the repository and must run anywhere).  Falls back to the portable library."""
+    global _SO, _lib
+    nat = os.path.join(_HERE, "_build", "librtdm_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "OUT=_build/librtdm_oracle_native.so",
+                               "CFLAGS=-O3 -march=native -fPIC -Wall -Wextra -std=c11"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        C.CDLL(nat)
+    except (subprocess.CalledProcessError, OSError):
+        return build()
+    if _SO != nat:
+        _SO, _lib = nat, None
+    return nat
+
+
 _lib = None
 
 
@@ -55,6 +72,8 @@ def lib():
         L.orc_bm_search.argtypes = [C.POINTER(BMParams), u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int,
                                     C.c_int, C.c_int, i16p, C.c_size_t, i32p, C.c_size_t]
         L.orc_bm_search.restype = None
+        L.orc_bm_set_legacy_right_clamp.argtypes = [C.c_int]
+        L.orc_bm_set_legacy_right_clamp.restype = None
         L.orc_validate_disparity.argtypes = [i16p, C.c_size_t, i32p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                              C.c_int, C.c_int]
         L.orc_validate_disparity.restype = None
@@ -152,6 +171,11 @@ def bm_search(lp, rp, row0, row1, **kw):
     lib().orc_bm_search(C.byref(p), _p(lp, C.c_uint8), W, _p(rp, C.c_uint8), W, W, H, row0, row1,
                         _p(disp, C.c_int16), W, _p(cost, C.c_int32), W)
     return disp, cost
+
+
+def set_legacy_right_clamp(on):
+    """Hazard H1 of rtdm_oracle.h: 1 = the OpenCV 3.x right-border clamp (over-reads the row)."""
+    lib().orc_bm_set_legacy_right_clamp(int(bool(on)))
 
 
 def valid_rect(W, H, **kw):

@@ -22,6 +22,34 @@
  *   - morphology sequence:       mf-sw.cpp:22-27; mf-sw.h:11-12
  * It is cross-checked by an independent brute-force implementation
  * (tests/bruteforce.py) and by known-answer properties (tests/test_oracle_*.py).
+ *
+ * KNOWN VERSION HAZARDS (places where OpenCV releases differ or where this restatement had to choose; none can be
+ * closed without the library, all are outside what the reference's own settings can distinguish unless noted):
+ *  H1 right-image border clamp in the SAD search (bm_oracle.c, rbase[]).  The window sample column j of the right
+ *     image is clamp(rofs+j, 0, W-D) + d here, as in OpenCV 4.x ("width-rofs-ndisp").  The 3.1-3.2 era the reference
+ *     links clamped to W-rofs-1 and let rptr[d] run past the end of the row (into the next row / the buffer's tail).
+ *     Affected: only windows that contain a sample column j > width1-1, i.e. (minD = 0) the LAST w/2 output columns
+ *     [W-w/2, W) of the search.  Those columns lie outside the valid rectangle and are masked; they reach the final
+ *     map only as voters of validateDisparity, whose targets are x2 in [x-D-1, x], so no pixel left of column
+ *     W-w/2-D-1 can change.  tests/test_oracle_bm.py::test_right_clamp_hazard_is_confined checks both statements.
+ *     orc_bm_set_legacy_right_clamp(1) selects the 3.x rule (next-row bytes as the over-read).
+ *  H2 cost plane width: 3.x's scalar path stores the cost through int* into a CV_16S plane; the SIMD
+ *     path and 4.x use short.  Identical whenever 2*cap*w*w < 32768 (all reference / BASELINE settings: <= 10478).
+ *     The oracle keeps int32.
+ *  H3 RGB2GRAY fixed point (rectify_oracle.c): 14-bit coefficients 4899/9617/1868, (.. + 8192) >> 14, as in OpenCV
+ *     2.x/3.x; 4.x switched the 8-bit path to 15 bits (9798/19235/3735, >> 15).  Differences are +-1 gray level on a
+ *     fraction of pixels; they would propagate into the prefilter.  The reference's era (3.1-3.2) is the 14-bit one.
+ *  H4 findContours border (objects_oracle.c, zero_border): OpenCV clears the 1-pixel image border before tracing
+ *     (3.x always; later releases copy with a border instead).  Affected: components touching the frame edge lose their
+ *     edge pixels in the bounding box (1 px per touched side).  A switch, default = the 3.x behaviour.
+ *  H5 reprojectImageTo3D (depth_oracle.c): Z = (float)(Zh / Wh) here; OpenCV multiplies by the reciprocal
+ *     (Z = Zh * (1/W) in double, then float).  A last-ulp float difference per pixel is possible; the reported mean is
+ *     taken over >= hundreds of pixels in double, so the effect is below the printed precision (estimator.cpp:259).
+ *  H6 remap INTER_LINEAR fixed point (rectify_oracle.c): weights from the 32x32 bilinear table in 15-bit fixed point,
+ *     (sum + 16384) >> 15, saturate_cast not reachable for convex weights.  OpenCV builds the table by rounding float
+ *     weights to short and fixing the sum to 32768 on the largest weight; the oracle's table construction follows that
+ *     rule, but the tie rule for "largest weight" is from memory.
+ *  H7 StereoSGBM (sgm_oracle.c): see that file's header; MODE_SGBM is restated from memory of stereosgbm.cpp 3.x.
  */
 #ifndef RTDM_ORACLE_H_
 #define RTDM_ORACLE_H_
@@ -74,6 +102,8 @@ void orc_bm_search(const orc_bm_params* p, const uint8_t* Lp, size_t lstep,
                    const uint8_t* Rp, size_t rstep, int W, int H,
                    int row0, int row1, int16_t* disp, size_t dstep_elems,
                    int32_t* cost, size_t cstep_elems);
+/* 0 (default): right-image border clamp of OpenCV 4.x; 1: the 3.x rule that over-reads the row (hazard H1 above). */
+void orc_bm_set_legacy_right_clamp(int on);
 void orc_validate_disparity(int16_t* disp, size_t dstep_elems, const int32_t* cost,
                             size_t cstep_elems, int W, int rows, int minD, int numD,
                             int disp12MaxDiff);

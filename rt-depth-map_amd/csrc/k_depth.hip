@@ -92,8 +92,9 @@ void launch_depth_stats(const int16_t* disp, size_t pitch_e, int W, int H, const
     double* mean = (double*)p; p += (size_t)n * 8;
     int* pcnt = (int*)p; p += (size_t)n * maxH * 4;
     int* counts = (int*)p;
-    const int big = 0x7fffffff;
-    (void)hipMemcpyAsync(minval, &big, 4, hipMemcpyHostToDevice, stream);
+    // initial minimum written on the device (0x7f7f7f7f is above any int16): an async copy from a stack local would
+    // only be safe if the runtime staged pageable sources at enqueue time
+    (void)hipMemsetAsync(minval, 0x7f, 4, stream);
     (void)hipMemcpyAsync(dreg, h_regions, (size_t)n * 16, hipMemcpyHostToDevice, stream);
     hipLaunchKernelGGL(k_depth_min, dim3(256), dim3(256), 0, stream, disp, pitch_e, W, H, minval);
     if (n > 0) {

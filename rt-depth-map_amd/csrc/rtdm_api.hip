@@ -28,6 +28,13 @@ static thread_local std::string g_hip_err;
 
 struct StageEvent { hipEvent_t a, b; int stage; int frames; };
 
+// Shape of a batched search launch, compared field by field (tune_strips).
+struct TuneKey {
+    int W, H, n, ncols, nrows, fuse;
+    bool operator==(const TuneKey& o) const { return W == o.W && H == o.H && n == o.n && ncols == o.ncols && nrows == o.nrows && fuse == o.fuse; }
+};
+struct TuneEntry { TuneKey key; int strips; };   // strips: 0 = seen once, not measured yet; -1 = measuring failed
+
 // A lane = one HIP stream plus its slice of the per-handle workspace.  A batch is cut into pieces that
 // alternate between two lanes, so that the latency-bound row kernels (left-right check, speckle
 // filter) of one piece run beside the VALU-bound SAD search of the other.
@@ -55,7 +62,7 @@ struct rtdm_bm {
     uint8_t *dLp, *dRp;            // prefiltered planes   [maxB][maxH][ppitch]
     uint8_t *dInL, *dInR;          // staging for the host entry points
     int16_t* dOut;                 //                      [maxB][maxH][maxW]
-    std::vector<std::pair<unsigned long long, int>> tuned;   // measured strip counts per (geometry, batch) shape
+    std::vector<TuneEntry> tuned;  // measured strip counts per work shape, least recently used first (<= 16 entries)
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
     int16_t* dHead;
@@ -290,47 +297,62 @@ static void stage_end(rtdm_bm* bm, hipStream_t s, StageEvent* ev)
 
 static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s);
 
-// Row strips per frame for the fast search of a batch, chosen by measurement the first time a (geometry, batch) shape is
-// seen and remembered in the handle: the model (fast_strips_model) is right on average, but neighbouring strip counts
-// differ by up to 5 % through scheduling effects it cannot see (profiles/r01_xcd_mapping_sweep.txt).  The search only
-// writes its own outputs, so timing it a few times on the caller's data is harmless.  Small batches (the reference
-// changes the ROI every frame) keep the model.  RTDM_AUTOTUNE=0 switches this off.
+// Row strips per frame for the fast search of a batch, chosen by measurement and remembered in the handle: the model
+// (fast_strips_model) is right on average, but neighbouring strip counts differ by up to 5 % through scheduling effects it
+// cannot see (profiles/r01_xcd_mapping_sweep.txt).  The search only writes its own outputs, so timing it a few times on
+// the caller's data is harmless.  The key is the SHAPE of the work (frame size, batch, searched columns and rows as
+// counts, not positions): a caller that moves a same-sized ROI around (estimator.cpp:53-54) keeps its entry.  A shape is
+// measured the SECOND time it is seen -- a caller whose ROI changes size every call never pays the ~30 extra launches and
+// the stream synchronisation -- and the table is a 16-entry LRU.  Small batches keep the model.  RTDM_AUTOTUNE=0: off.
 static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plane16W disp, const BMGeom& g, int n, hipStream_t s, bool fuse)
 {
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("RTDM_AUTOTUNE"); enabled = e ? atoi(e) : 1; }
     if (!enabled || n < 16 || getenv("RTDM_FAST_WGS")) return 0;
-    const unsigned long long key = ((unsigned long long)g.W << 48) ^ ((unsigned long long)g.H << 36) ^ ((unsigned long long)n << 24) ^
-                                   ((unsigned long long)g.cx0 << 12) ^ (unsigned long long)g.cx1 ^ ((unsigned long long)g.vy0 << 20) ^
-                                   ((unsigned long long)g.vy1 << 8) ^ ((unsigned long long)fuse << 63);
-    for (const auto& t : bm->tuned) if (t.first == key) return t.second;
-    const int model = fast_strips_model(g, n), cap = (g.vy1 - g.vy0 + 15) / 16;
-    int best = model;
-    float best_ms = 1e30f;
-    hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
-    static const float f[] = {0.6f, 0.7f, 0.8f, 0.9f, 1.0f, 1.1f, 1.2f, 1.35f, 1.5f, 1.75f};
-    int seen[10], nseen = 0;
-    for (float fk : f) {
-        const int c = std::max(1, std::min(cap, (int)(model * fk + 0.5f)));
-        bool dup = false;
-        for (int i = 0; i < nseen; ++i) dup |= seen[i] == c;
-        if (dup) continue;
-        seen[nseen++] = c;
-        launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);          // warm
-        float ms = 1e30f;
-        for (int rep = 0; rep < 2; ++rep) {
-            (void)hipEventRecord(a, s);
-            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);
-            (void)hipEventRecord(b, s);
-            float t = 0.f;
-            if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&t, a, b) == hipSuccess) ms = std::min(ms, t);
+    TuneKey key{g.W, g.H, n, g.cx1 - g.cx0, g.vy1 - g.vy0, fuse ? 1 : 0};
+    for (size_t i = 0; i < bm->tuned.size(); ++i) {
+        if (!(bm->tuned[i].key == key)) continue;
+        TuneEntry e = bm->tuned[i];
+        bm->tuned.erase(bm->tuned.begin() + (long)i);              // most recently used goes to the back
+        if (e.strips == 0) {
+            e.strips = -1;                                          // being measured: a failure below leaves the model in charge
+            const int model = fast_strips_model(g, n), cap = (g.vy1 - g.vy0 + 15) / 16;
+            int best = model;
+            float best_ms = 1e30f;
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) == hipSuccess) {
+                if (hipEventCreate(&b) == hipSuccess) {
+                    static const float f[] = {0.6f, 0.7f, 0.8f, 0.9f, 1.0f, 1.1f, 1.2f, 1.35f, 1.5f, 1.75f};
+                    int seen[10], nseen = 0;
+                    for (float fk : f) {
+                        const int c = std::max(1, std::min(cap, (int)(model * fk + 0.5f)));
+                        bool dup = false;
+                        for (int k = 0; k < nseen; ++k) dup |= seen[k] == c;
+                        if (dup) continue;
+                        seen[nseen++] = c;
+                        launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);          // warm
+                        float ms = 1e30f;
+                        for (int rep = 0; rep < 2; ++rep) {
+                            (void)hipEventRecord(a, s);
+                            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);
+                            (void)hipEventRecord(b, s);
+                            float t = 0.f;
+                            if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&t, a, b) == hipSuccess) ms = std::min(ms, t);
+                        }
+                        if (ms < best_ms) { best_ms = ms; best = c; }
+                    }
+                    e.strips = best;
+                    (void)hipEventDestroy(b);
+                }
+                (void)hipEventDestroy(a);
+            }
         }
-        if (ms < best_ms) { best_ms = ms; best = c; }
+        bm->tuned.push_back(e);
+        return e.strips > 0 ? e.strips : 0;
     }
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    bm->tuned.push_back(std::make_pair(key, best));
-    return best;
+    if (bm->tuned.size() >= 16) bm->tuned.erase(bm->tuned.begin());  // least recently used
+    bm->tuned.push_back(TuneEntry{key, 0});                           // first sighting: remember, keep the model
+    return 0;
 }
 
 // One chunk (n <= maxB) of device-resident frames, enqueued on `s`.  The row kernels move 8 columns per 128-bit
@@ -386,13 +408,15 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
             static const bool async_border = [] { const char* e = getenv("RTDM_BORDER_ASYNC"); return !e || atoi(e) != 0; }();
             const bool side = async_border && border_search_supported(g) && n >= 16;
             const bool fuse = border_search_supported(g) && !separate && !side;
+            // (measured, if at all, before the side stream forks: nothing else runs beside the timed launches)
+            const int strips = tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse);
             if (side) {
                 HIPC(hipEventRecord(ln.fork, s));
                 HIPC(hipStreamWaitEvent(ln.side, ln.fork, 0));
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, ln.side, lx0, lx1, rx0, rx1);
                 HIPC(hipEventRecord(ln.join, ln.side));
             }
-            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse));
+            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, strips);
             if (side) {
                 HIPC(hipStreamWaitEvent(s, ln.join, 0));
             } else if (fuse) {

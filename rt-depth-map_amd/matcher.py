@@ -30,7 +30,7 @@ class HIPMatcher:
         if getattr(self, "_h", None) is not None and self._h:
             try:
                 B.lib().rtdm_bm_destroy(self._h)
-            except TypeError:       # interpreter shutdown: the module globals are already gone
+            except (TypeError, AttributeError):       # interpreter shutdown: the module globals are already gone
                 pass
             self._h = None
 
@@ -130,7 +130,7 @@ class HIPSemiGlobalMatcher:
         if getattr(self, "_h", None) is not None and self._h:
             try:
                 B.lib().rtdm_sgm_destroy(self._h)
-            except TypeError:
+            except (TypeError, AttributeError):
                 pass
             self._h = None
 
@@ -175,7 +175,7 @@ class HIPMorphologicalFilter:
         if getattr(self, "_h", None) is not None and self._h:
             try:
                 B.lib().rtdm_morph_destroy(self._h)
-            except TypeError:
+            except (TypeError, AttributeError):
                 pass
             self._h = None
 
@@ -229,7 +229,7 @@ class HIPRectifier:
         if getattr(self, "_h", None) is not None and self._h:
             try:
                 B.lib().rtdm_rectify_destroy(self._h)
-            except TypeError:
+            except (TypeError, AttributeError):
                 pass
             self._h = None
 
@@ -295,7 +295,7 @@ class HIPObjectDetector:
         if getattr(self, "_h", None) is not None and self._h:
             try:
                 B.lib().rtdm_objects_destroy(self._h)
-            except TypeError:
+            except (TypeError, AttributeError):
                 pass
             self._h = None
 

@@ -12,6 +12,8 @@ path.  Two modes:
 
 One process per GPU; nothing here touches the compute path itself (`compute` is a callable).
 """
+import contextlib
+
 import torch
 
 
@@ -26,51 +28,145 @@ def shard_sizes(n_frames, world):
     return [partition(n_frames, world, r)[1] for r in range(world)]
 
 
+class _Streams:
+    """The two queues of the pipeline: `main` (the caller's current stream: compute) and `comm` (a side
+    stream from which the collectives are issued).  On a CPU device both are the program order."""
+
+    def __init__(self, device):
+        self.cuda = device.type == "cuda"
+        if self.cuda:
+            self.main = torch.cuda.current_stream(device)
+            self.comm = torch.cuda.Stream(device)
+            self.comm.wait_stream(self.main)          # the caller's inputs are ready on `main`
+
+    def on_comm(self):
+        return torch.cuda.stream(self.comm) if self.cuda else contextlib.nullcontext()
+
+    def mark(self, comm=False):
+        """An event at the current tail of `main` (or `comm`); None on CPU."""
+        if not self.cuda:
+            return None
+        ev = torch.cuda.Event()
+        ev.record(self.comm if comm else self.main)
+        return ev
+
+    def comm_waits(self, ev):
+        if ev is not None:
+            self.comm.wait_event(ev)
+
+    def main_waits(self, ev):
+        if ev is not None:
+            self.main.wait_event(ev)
+
+    def join(self):
+        if self.cuda:
+            self.main.wait_stream(self.comm)
+
+
 def scatter_compute_gather(dist, left, right, n_frames, frame_shape, compute, device, out_dtype=torch.int16,
-                           chunk=None):
+                           chunk=None, compute_into=None):
     """left/right: uint8 [n_frames, H, W] on rank 0 (ignored elsewhere).  Returns the gathered
-    [n_frames, H, W] disparities on rank 0 (None elsewhere).  `compute(L, R) -> D` runs on this
-    rank's shard (tensors on `device`).  Shards are padded to the largest block so that the
-    collectives see equal sizes; `chunk` (frames) bounds the size of each scatter/gather so that
-    communication of chunk k+1 can overlap the compute of chunk k on a separate stream."""
+    [n_frames, H, W] disparities on rank 0 (None elsewhere).  `compute(L, R) -> D` runs on this rank's
+    shard (tensors on `device`); `compute_into(L, R, out)`, if given, is used instead and writes `out`.
+
+    The shard is cut into chunks of `chunk` frames and pipelined over two buffer sets: while chunk k is
+    computed on the caller's stream, the scatter of chunk k+1 and the gather of chunk k-1 run from a side
+    stream (collectives are issued asynchronously from it; their completion is joined to the compute
+    stream with Work.wait(), which does not block the host on a GPU).  The root passes VIEWS of its frames
+    to the scatter and views of the result to the gather; only a ragged last chunk (a rank whose block is
+    one frame shorter) goes through a padded temporary."""
     world, rank = dist.get_world_size(), dist.get_rank()
     H, W = frame_shape
     counts = shard_sizes(n_frames, world)
-    mine = counts[rank]
-    cap = max(counts)
-    step = cap if not chunk else min(chunk, cap)
-    out_local = torch.empty((cap, H, W), dtype=out_dtype, device=device)
-    gathered = [torch.empty((cap, H, W), dtype=out_dtype, device=device) for _ in range(world)] if rank == 0 else None
-    for c0 in range(0, cap, step):
-        c1 = min(c0 + step, cap)
-        m = c1 - c0
-        lbuf = torch.empty((m, H, W), dtype=torch.uint8, device=device)
-        rbuf = torch.empty((m, H, W), dtype=torch.uint8, device=device)
-        lsrc = rsrc = None
-        if rank == 0:
-            lsrc, rsrc = [], []
-            for r in range(world):
-                s, cnt = partition(n_frames, world, r)
-                lo, hi = min(c0, cnt), min(c1, cnt)
-                lp = torch.zeros((m, H, W), dtype=torch.uint8, device=device)
-                rp = torch.zeros((m, H, W), dtype=torch.uint8, device=device)
+    starts = [partition(n_frames, world, r)[0] for r in range(world)]
+    mine, cap = counts[rank], max(counts)
+    step = cap if not chunk else max(1, min(chunk, cap))
+    chunks = [(c0, min(c0 + step, cap)) for c0 in range(0, cap, step)]
+    st = _Streams(device)
+    NB = 2
+    lbuf = [torch.empty((step, H, W), dtype=torch.uint8, device=device) for _ in range(NB)]
+    rbuf = [torch.empty((step, H, W), dtype=torch.uint8, device=device) for _ in range(NB)]
+    obuf = [torch.empty((step, H, W), dtype=out_dtype, device=device) for _ in range(NB)]
+    out = torch.empty((n_frames, H, W), dtype=out_dtype, device=device) if rank == 0 else None
+    in_free = [None] * NB       # event on main: the compute that read lbuf/rbuf[b] has been enqueued and finished
+    out_busy = [None] * NB      # Work of the gather that reads obuf[b]
+    keep = []                   # temporaries referenced by in-flight collectives
+
+    def src_views(frames, c0, c1):
+        """What the root hands to the scatter for chunk [c0, c1): one [m, H, W] tensor per rank."""
+        m, lst = c1 - c0, []
+        for r in range(world):
+            lo, hi = min(c0, counts[r]), min(c1, counts[r])
+            v = frames[starts[r] + lo:starts[r] + hi]
+            if v.device != device:
+                v = v.to(device, non_blocking=True)
+            if hi - lo < m:                         # ragged: this rank's block ends inside the chunk
+                p = torch.zeros((m, H, W), dtype=torch.uint8, device=device)
                 if hi > lo:
-                    lp[:hi - lo] = left[s + lo:s + hi].to(device)
-                    rp[:hi - lo] = right[s + lo:s + hi].to(device)
-                lsrc.append(lp); rsrc.append(rp)
-        dist.scatter(lbuf, lsrc, src=0)
-        dist.scatter(rbuf, rsrc, src=0)
+                    p[:hi - lo] = v
+                v = p
+            lst.append(v.contiguous())
+        keep.extend(lst)
+        return lst
+
+    def issue_scatter(k):
+        b, (c0, c1) = k % NB, chunks[k]
+        m = c1 - c0
+        with st.on_comm():
+            st.comm_waits(in_free[b])
+            ls = src_views(left, c0, c1) if rank == 0 else None
+            rs = src_views(right, c0, c1) if rank == 0 else None
+            return (dist.scatter(lbuf[b][:m], ls, src=0, async_op=True),
+                    dist.scatter(rbuf[b][:m], rs, src=0, async_op=True))
+
+    def issue_gather(k, done):
+        b, (c0, c1) = k % NB, chunks[k]
+        m = c1 - c0
+        with st.on_comm():
+            st.comm_waits(done)
+            dst, fix = None, []
+            if rank == 0:
+                dst = []
+                for r in range(world):
+                    lo, hi = min(c0, counts[r]), min(c1, counts[r])
+                    if hi - lo == m:
+                        dst.append(out[starts[r] + lo:starts[r] + hi])
+                    else:
+                        t = torch.empty((m, H, W), dtype=out_dtype, device=device)
+                        dst.append(t); fix.append((t, starts[r] + lo, hi - lo))
+                keep.extend(dst)
+            # collectives move raw bytes: gloo has no int16 kernels, and the payload is opaque anyway
+            wk = dist.gather(obuf[b][:m].view(torch.uint8),
+                             [d.view(torch.uint8) for d in dst] if rank == 0 else None, dst=0, async_op=True)
+            if fix:
+                wk.wait()                              # comm stream waits (host too on CPU); then the ragged tails
+                for t, s0, cnt in fix:
+                    if cnt > 0:
+                        out[s0:s0 + cnt] = t[:cnt]
+            return wk
+
+    pend = issue_scatter(0)
+    for k, (c0, c1) in enumerate(chunks):
+        b = k % NB
+        nxt = issue_scatter(k + 1) if k + 1 < len(chunks) else None
+        for wk in pend:
+            wk.wait()                                  # main waits for chunk k's inputs
+        if out_busy[b] is not None:
+            out_busy[b].wait()                         # obuf[b] is free again (gather of chunk k-2)
         live = max(0, min(c1, mine) - c0)
         if live > 0:
-            out_local[c0:c0 + live] = compute(lbuf[:live], rbuf[:live])
-    # collectives move raw bytes: gloo has no int16 kernels, and the payload is opaque anyway
-    dist.gather(out_local.view(torch.uint8), [g.view(torch.uint8) for g in gathered] if rank == 0 else None, dst=0)
-    if rank != 0:
-        return None
-    out = torch.empty((n_frames, H, W), dtype=out_dtype, device=device)
-    for r in range(world):
-        s, cnt = partition(n_frames, world, r)
-        out[s:s + cnt] = gathered[r][:cnt]
+            if compute_into is not None:
+                compute_into(lbuf[b][:live], rbuf[b][:live], obuf[b][:live])
+            else:
+                obuf[b][:live] = compute(lbuf[b][:live], rbuf[b][:live])
+        done = st.mark()
+        in_free[b] = done
+        out_busy[b] = issue_gather(k, done)
+        pend = nxt
+    for wk in out_busy:
+        if wk is not None:
+            wk.wait()
+    st.join()
     return out
 
 

@@ -186,3 +186,29 @@ def test_parameter_validation(oracle, synth):
 def test_too_narrow_image_is_all_filtered(oracle):
     img = np.random.default_rng(0).integers(0, 255, (40, 30), dtype=np.uint8)
     assert (oracle.bm_compute(img, img, numDisparities=32, blockSize=5) == FIL).all()
+
+
+# ---- version hazard H1 (oracle/rtdm_oracle.h): right-image border clamp ---------------------------
+def test_right_clamp_hazard_is_confined(oracle, synth):
+    """OpenCV 3.x clamps the right sample base to W-rofs-1 and over-reads the row, 4.x (and the oracle) to W-D.
+    The choice can only change the search output in the last w/2 columns, which lie outside the valid rectangle;
+    in the final map it can only reach pixels through their left-right-check votes, i.e. columns >= W - w/2 - D - 1."""
+    W, H, D, w = 160, 120, 32, 9
+    r = w // 2
+    L, R = pair(synth, W, H, D, seed=5)
+    lp, rp = oracle.prefilter_xsobel(L, 31), oracle.prefilter_xsobel(R, 31)
+    kw = dict(numDisparities=D, blockSize=w)
+    d0, _ = oracle.bm_search(lp, rp, r, H - r - 1, **kw)
+    f0 = oracle.bm_compute(L, R, **kw)
+    oracle.set_legacy_right_clamp(True)
+    try:
+        d1, _ = oracle.bm_search(lp, rp, r, H - r - 1, **kw)
+        f1 = oracle.bm_compute(L, R, **kw)
+    finally:
+        oracle.set_legacy_right_clamp(False)
+    diff = d0 != d1
+    assert not diff[:, :W - r].any()
+    assert diff[:, W - r:].any()                      # the switch is live
+    fd = f0 != f1
+    assert not fd[:, :W - r - D - 1].any()
+    assert fd.mean() < 0.01                           # a handful of pixels near the right edge at most

@@ -46,7 +46,7 @@ def _worker(rank, world, port, chunk, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,chunk", [(2, None), (2, 2), (3, None)])
+@pytest.mark.parametrize("world,chunk", [(2, None), (2, 2), (2, 1), (3, None), (3, 2)])
 def test_sharded_equals_single_rank(world, chunk):
     pkg = load()
     L, R = pkg.synth.make_stream(0, NF, W, H, D)
