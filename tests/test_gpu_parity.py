@@ -298,9 +298,17 @@ def test_device_api_is_ordered_on_the_callers_stream(pkg, synth):
         m.compute_device(L.contiguous(), R.contiguous(), out, st)
         return out                                   # consumed by torch copies right away, no sync
 
-    class Solo:
-        get_world_size = staticmethod(lambda: 1); get_rank = staticmethod(lambda: 0)
-        scatter = staticmethod(lambda t, l, src=0: t.copy_(l[0])); gather = staticmethod(lambda t, l, dst=0: l[0].copy_(t))
+    class Work:                                       # what an asynchronous collective hands back: wait() orders the
+        def __init__(self):                           # CURRENT stream behind the stream the collective was issued from
+            self.ev = torch.cuda.Event(); self.ev.record(torch.cuda.current_stream())
+        def wait(self):
+            torch.cuda.current_stream().wait_event(self.ev)
+
+    class Solo:                                       # world of one without a process group (the real RCCL group of size
+        get_world_size = staticmethod(lambda: 1)      # one is exercised by tests/test_gpu_round2.py through bench.py)
+        get_rank = staticmethod(lambda: 0)
+        scatter = staticmethod(lambda t, l, src=0, async_op=False: (t.copy_(l[0]), Work())[1])
+        gather = staticmethod(lambda t, l, dst=0, async_op=False: (l[0].copy_(t), Work())[1])
     for chunk in (3, None):
         out = sh.scatter_compute_gather(Solo, left, right, N, (H, W), compute, dev, chunk=chunk)
         torch.cuda.synchronize()
