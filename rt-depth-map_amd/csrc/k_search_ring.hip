@@ -1,0 +1,464 @@
+// k_search_ring.hip -- K2, ring variant: the SAD window search with NO leaving-row recomputation.
+//
+// k_search_fast keeps the w-row window sums of a pixel in registers and pays for every row twice: once when it enters
+// the window and once, w rows later, when it is recomputed from an LDS ring and subtracted.  Here a pixel's registers
+// hold the running PREFIX sums over the rows of its strip instead,
+//       P(t)[d] = sum_{rows 0..t} H(row)[d]            H = the horizontal w-byte SAD of one row
+//       S(t)[d] = P(t)[d] - P(t-w)[d]                   the w x w window sum
+// in a ring of w+1 register slots: v_qsad_pk_u16_u8 takes P(t-1) as its accumulator operand and writes P(t) into the
+// slot of the dead P(t-w-1), so a row costs its quad-SADs once plus one subtraction per two disparities.  Ring slots
+// are compile-time registers: one trip of the row loop is one round of the ring, unrolled, every row step a copy with
+// its own register operands (a switch over the slot inside a rolled loop made the register allocator copy and spill
+// the ring at every merge).
+//
+// A pixel's ring is (w+1) * D/2 registers (320 at D = 64, w = 9), so the D disparities of a pixel are split over the TWO
+// lanes l and l+32 of a wave (160 ring registers each, 2 waves per SIMD).  Selection wants all D values of a pixel in
+// one lane: rows are processed in PAIRS, and after the pair one v_permlane32_swap per register hands the lower lane both
+// halves of row t and the upper lane both halves of row t+1 -- each lane then runs the single-lane selection of
+// rtdm_select.h once per two rows, so nothing is computed twice.
+//
+// Mapping: workgroup = 128 output columns x `rs` rows of one frame; wave = byte phase phi, lanes l and l+32 = column
+// x_tile + phi + 4 (l & 31).  The four waves never synchronise: each stages ITS byte-shifted copy of the entering rows
+// (128 dwords at D = 64, padded) into its own LDS slice, two rows ahead of their use, and the LDS queue of a wave is in
+// order.  The texture sum is a prefix ring too (one dword per lane and slot, in LDS).  Only columns whose window needs
+// no border clamping are handled here; the border columns go to k_search_border.
+// Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
+//
+// Measured instruction costs on gfx950 that shaped this (tools/ubench_valu.hip, SIMD cycles per wave-instruction):
+// v_qsad/v_mqsad_pk_u16_u8 16.4; v_add/sub/and/xor/mov 2.6; everything else used here (packed u16 ops, v_perm,
+// v_cndmask, v_min3, v_cmp, shifts, v_sad_u8) 4.2-4.7; v_permlane32_swap 8.1.
+#include "rtdm_select.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#ifndef RING_PRELOAD      // 1: the first row of the next pair is read from LDS before the selection (needs ~25 more VGPRs)
+#define RING_PRELOAD 0
+#endif
+#ifndef RING_ABL          // timing-only ablations (tools/ring_ablate.sh): 1 no selection, 2 no stores, 3 no global loads,
+#define RING_ABL 0        // 4 no quad-SADs, 5 no swaps, 6 no swaps + no selection.  Outputs are wrong for n != 0.
+#endif
+#ifndef RING_LDS_SELECT   // 1: select_disparity_lds (fetches through LDS), 0: select_disparity (v_cndmask tree)
+#define RING_LDS_SELECT 1
+#endif
+
+#ifdef RING_STAMPS        // diagnostic build only (tools/ring_stamps.sh): where a row pair spends its cycles
+__device__ unsigned long long ring_stamps[8];
+#define RING_STAMP(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                           stamp_sum[i] += t_ - stamp_last; stamp_last = t_; } while (0)
+extern "C" void rtdm_debug_ring_stamps(unsigned long long* out, int reset)
+{
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ring_stamps), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(ring_stamps), z, sizeof z); }
+}
+#else
+#define RING_STAMP(i) do { } while (0)
+#endif
+
+namespace rtdm {
+
+struct RingGeom {
+    int x0, nx;          // output-column range [x0, x0+nx) handled by this kernel
+    int rs;              // output rows per workgroup
+    uint32_t lastmask;   // byte mask of the last (partial) window piece
+    int tiles, strips;   // column tiles x row strips per frame
+    unsigned nitems;     // workgroups over the whole batch
+};
+
+template <int D, int WS>
+struct RingCfg {
+    static constexpr int NP = (WS + 3) / 4;        // 4-byte pieces of a window row
+    static constexpr int W1 = WS + 1;              // ring slots
+    static constexpr int DL = D / 2;               // disparities per lane
+    static constexpr int NGL = DL / 4;             // quad-SAD groups per lane
+    static constexpr int NRL = DL / 2;             // packed u16x2 registers per lane and slot
+    static constexpr int NW = NGL + NP - 1;        // distinct 8-byte right windows per lane and row
+    static constexpr int LWD = 32 + NP;            // dwords of the wave's copy of the left row
+    static constexpr int RWD = 32 + D / 4 + NP;    //                                 right row
+    static constexpr int ITEMS = (LWD + RWD + 63) / 64;
+    static constexpr int SLOT = ITEMS * 64;        // padded: every lane stores every item, no exec masking
+    static constexpr int NSLOT = 3;                // staged rows in flight per wave
+    static constexpr int STG = (NSLOT * SLOT + W1 * 64 + 3) & ~3;   // dwords per wave: staged rows + the texture prefix ring
+    static constexpr int WAVE_LDS = STG + 64 * SEL_LANE_DWORDS;     // + the selection's per-lane records (rtdm_select.h)
+    static constexpr int TILE = 128;
+};
+
+template <int D, int WS>
+struct RingState { uint64_t P[RingCfg<D, WS>::W1][RingCfg<D, WS>::NGL]; };   // only ever indexed with constants: registers
+
+// The registers a lane needs of one staged row: its NW right windows (8 bytes each) and its NP left pieces.
+template <int D, int WS>
+struct RowRegs { uint64_t win[RingCfg<D, WS>::NW]; uint32_t l[RingCfg<D, WS>::NP]; };
+
+// lp / rp: this lane's left pieces / right windows of the staged row in LDS.
+template <int D, int WS>
+__device__ __forceinline__ void ring_load_row(const uint32_t* __restrict__ lp, const uint32_t* __restrict__ rp, RowRegs<D, WS>& rw)
+{
+    using C = RingCfg<D, WS>;
+    // 64-bit operands want even-aligned VGPR pairs: windows at odd dword offsets are loaded through a second pointer
+    // whose index is laundered, so that they get their own ds_read2_b32 instead of v_mov rebuilds.
+    // Issue order = order of first use (the LDS returns data in order): the left pieces, then the windows by index.
+    int one = 1;
+    asm volatile("" : "+v"(one));
+    const uint32_t* rpo = rp + one;
+#pragma unroll
+    for (int k = 0; k < C::NP; ++k) rw.l[k] = lp[k];
+#pragma unroll
+    for (int j = 0; j < C::NW; ++j) {
+        const uint32_t* wp = (j & 1) ? rpo + (j - 1) : rp + j;
+        rw.win[j] = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
+    }
+}
+
+// One row step on ring slot K: P[K] = P[K-1] + H(row), S = P[K] - P[K+1] (the slot that holds P(t-w));
+// tnew += the row's texture term sum |L - cap|.
+template <int D, int WS, int K, int NRLc>
+__device__ __forceinline__ void ring_step(RingState<D, WS>& st, const RowRegs<D, WS>& rw, uint32_t lastmask, uint32_t capb,
+                                          uint32_t& tnew, uint32_t (&S)[NRLc])
+{
+    using C = RingCfg<D, WS>;
+    auto& P = st.P;
+    constexpr int NP = C::NP, NGL = C::NGL, W1 = C::W1;
+    constexpr int KP = (K + W1 - 1) % W1, KO = (K + 1) % W1;
+    uint32_t l[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) l[k] = rw.l[k];
+    l[NP - 1] &= lastmask;
+#pragma unroll
+    for (int k = 0; k < NP - 1; ++k) tnew = __builtin_amdgcn_sad_u8(l[k], capb, tnew);
+    tnew = __builtin_amdgcn_msad_u8(capb, l[NP - 1], tnew);   // zero bytes of the reference are skipped
+#pragma unroll
+    for (int j = 0; j < C::NW; ++j) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int gi = j - k;
+            if (gi >= 0 && gi < NGL) {
+                const uint64_t acc = k == 0 ? P[KP][gi] : P[K][gi];
+#if RING_ABL == 4
+                P[K][gi] = acc + (rw.win[j] ^ l[k]);
+#else
+                if (k == NP - 1) P[K][gi] = __builtin_amdgcn_mqsad_pk_u16_u8(rw.win[j], l[k], acc);
+                else             P[K][gi] = __builtin_amdgcn_qsad_pk_u16_u8(rw.win[j], l[k], acc);
+#endif
+            }
+        }
+    }
+#pragma unroll
+    for (int gi = 0; gi < NGL; ++gi) {
+        // plain 32-bit subtractions of the packed pairs (v_sub_u32 issues at 1.6x the rate of v_pk_sub_u16): a strip is
+        // short enough that no prefix sum leaves 16 bits (ring_rows_cap), so each half of P(t) is >= that half of P(t-w)
+        // and no borrow crosses from the low half into the high one
+        S[2 * gi] = (uint32_t)P[K][gi] - (uint32_t)P[KO][gi];
+        S[2 * gi + 1] = (uint32_t)(P[K][gi] >> 32) - (uint32_t)(P[KO][gi] >> 32);
+    }
+}
+
+// Orders everything that produces v[] before whatever follows (no instruction is emitted).
+template <int N>
+__device__ __forceinline__ void pin(uint32_t (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
+}
+
+// compile-time loop over the row pairs of one trip round the ring; f(pair index constant) returns false to stop
+template <typename F, int... U>
+__device__ __forceinline__ void ring_for_pairs(std::integer_sequence<int, U...>, F&& f)
+{ (void)(f(std::integral_constant<int, U>{}) && ...); }
+
+template <int D, int WS>
+__global__ __launch_bounds__(256, 2) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg)
+{
+    using C = RingCfg<D, WS>;
+    constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS;
+    static_assert(W1 % 2 == 0, "rows go in pairs: the block size must be odd");
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+
+    const unsigned fi = blockIdx.x;
+    if (fi >= rg.nitems) return;
+    const int b_tile = (int)(fi % rg.tiles), b_strip = (int)((fi / rg.tiles) % rg.strips), f = (int)(fi / (rg.tiles * rg.strips));
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int phi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int x_tile = rg.x0 + b_tile * C::TILE;
+    const int x = x_tile + phi + 4 * p;
+    const bool active = x < rg.x0 + rg.nx;
+    const int ys0 = g.vy0 + b_strip * rg.rs;
+    const int ys1 = min(ys0 + rg.rs, g.vy1);
+    if (ys0 >= ys1) return;
+    const int r = g.r;
+    const uint8_t* Lb = Lp.base + (size_t)f * Lp.frame;
+    const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
+    const int Lbase = g.lofs + x_tile - r + phi;   // image column of byte 0 of this wave's copy (left)
+    const int Rbase = g.rofs + x_tile - r + phi;   //                                            (right)
+    const uint32_t capb = (uint32_t)(g.cap + 1) * 0x01010101u;
+
+    uint32_t* stg = lds + phi * C::WAVE_LDS;       // this wave's slice: nothing below is shared between waves
+    uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][64]
+#if RING_LDS_SELECT
+    uint32_t* scr = stg + C::STG + lane * SEL_LANE_DWORDS;   // this lane's selection record
+#endif
+
+    // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
+    // Unconditional loads: bytes past a row's end only ever reach lanes that are not `active`, and the prefiltered planes
+    // are allocated with 1 KB of slack behind the last row (rtdm_api.hip).  Two rows of loads are in flight (pre[0/1]).
+    const int row0 = ys0 - r;
+    const int Hm1 = g.H - 1;
+    const uint8_t* src[ITEMS];                      // where the next row to be issued starts, per item
+    int it_sh[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = lane + it * 64;
+        const bool isr = idx >= LWD;
+        const int m = isr ? idx - LWD : idx;
+        const int col = (isr ? Rbase : Lbase) + 4 * m;
+        src[it] = (isr ? Rb : Lb) + (size_t)row0 * Lp.pitch + (col & ~3);
+        it_sh[it] = col & 3;
+    }
+    int next_row = row0;
+    uint32_t pre[2][ITEMS][2];
+    auto issue = [&](auto Sc) {                     // loads of the next row into register set Sc; rows past H-1 repeat H-1
+        constexpr int SET = decltype(Sc)::value;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+#if RING_ABL == 3
+            pre[SET][it][0] = (uint32_t)next_row * 0x01020304u + lane; pre[SET][it][1] = (uint32_t)next_row * 0x04030201u ^ lane;
+#else
+            pre[SET][it][0] = *(const uint32_t*)(src[it]);
+            pre[SET][it][1] = *(const uint32_t*)(src[it] + 4);
+#endif
+        }
+        const size_t adv = next_row < Hm1 ? Lp.pitch : 0;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) src[it] += adv;
+        ++next_row;
+    };
+    auto commit = [&](auto Sc, int slot) {
+        constexpr int SET = decltype(Sc)::value;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t v = __builtin_amdgcn_alignbyte(pre[SET][it][1], pre[SET][it][0], (uint32_t)it_sh[it]);
+            stg[slot * SLOT + lane + it * 64] = v + 0x01010101u;
+        }
+        __builtin_amdgcn_wave_barrier();           // the wave's later reads stay behind these writes (LDS is in order per wave)
+    };
+    using Set0 = std::integral_constant<int, 0>;
+    using Set1 = std::integral_constant<int, 1>;
+
+    RingState<D, WS> st;
+#pragma unroll
+    for (int k = 0; k < W1; ++k)
+#pragma unroll
+        for (int i = 0; i < NGL; ++i) st.P[k][i] = 0;
+#pragma unroll
+    for (int k = 0; k < W1; ++k) ptr[k * 64 + lane] = 0;
+    uint32_t pt = 0;                                // texture prefix sum of the rows so far
+
+    const int nsteps = (ys1 - ys0) + WS - 1;
+    const int nsteps2 = (nsteps + 1) & ~1;          // rows go in pairs; a padded last row is computed and dropped
+    issue(Set0{}); issue(Set1{});
+    commit(Set0{}, 0); commit(Set1{}, 1);           // rows 0 and 1 -> slots 0 and 1
+    issue(Set0{});                                  // row 2: committed at the end of step 0
+
+    int16_t* db = disp.base + (size_t)f * disp.frame_e;
+    const int col = g.lofs + x;
+    const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
+
+    uint32_t S0[NRL], S1[NRL];
+    int ts0 = 0, ts1 = 0;
+#ifdef RING_STAMPS
+    unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
+#endif
+    // Row t is read from LDS slot t mod 3, where it was put two steps earlier.  Step t issues the global loads of row
+    // t+3 at its start and, at its end, writes row t+2 (issued one step earlier) to LDS -- BEHIND the step's quad-SADs
+    // (the empty asm on S pins that order: left alone the compiler sinks the SADs below the commit and every step then
+    // waits for its loads).  Rows past the strip's last are loaded and staged too (clamped to the frame) and never read:
+    // no branch in the step.
+    int sl_cur = 0;                                 // LDS slot of row t
+    RowRegs<D, WS> ra;
+    const auto lds_row = [&](int slot, RowRegs<D, WS>& rw) {
+        // (laundered indices: ONE base register per copy, window offsets fold into the ds_read immediates)
+        int li = slot * SLOT + p, ri = slot * SLOT + LWD + p + h * NGL;
+        asm volatile("" : "+v"(li), "+v"(ri));
+        ring_load_row<D, WS>(stg + li, stg + ri, rw);
+    };
+    auto step = [&](auto Kc, const RowRegs<D, WS>& rw, uint32_t (&S)[NRL], int& ts) {
+        constexpr int K = decltype(Kc)::value;            // ring slot of row t: a compile-time register set
+        using SetIn = std::integral_constant<int, (K + 1) & 1>;    // row t+3 goes where row t+1 was
+        using SetOut = std::integral_constant<int, K & 1>;         // row t+2
+        issue(SetIn{});
+        uint32_t tnew = 0;
+        ring_step<D, WS, K>(st, rw, rg.lastmask, capb, tnew, S);
+        constexpr int KO = (K + 1) % W1;
+        pt += tnew;
+        const uint32_t told = ptr[KO * 64 + lane];                // prefix sum w rows back (0 while the window fills)
+        ptr[K * 64 + lane] = pt;
+        ts = (int)(pt - told);
+        const int sl_new = sl_cur == 0 ? 2 : sl_cur - 1;            // slot of row t+2 = (t + 2) mod 3
+        sl_cur = sl_cur == 2 ? 0 : sl_cur + 1;
+        pin(S);
+        commit(SetOut{}, sl_new);
+    };
+#if RING_PRELOAD
+    lds_row(0, ra);
+#endif
+
+    // One trip of the outer loop = one round of the ring (W1 rows, W1 is even), unrolled: every row step has its ring
+    // slot -- its registers -- fixed at compile time.
+    for (int t0 = 0; t0 < nsteps2; t0 += W1) {
+        ring_for_pairs(std::make_integer_sequence<int, W1 / 2>{}, [&](auto Uc) -> bool {
+            constexpr int U = 2 * decltype(Uc)::value;
+            const int t = t0 + U;
+            if (t >= nsteps2) return false;
+            RING_STAMP(0);                                          // (loop overhead + whatever precedes the pair)
+#if !RING_PRELOAD
+            lds_row(sl_cur, ra);
+#endif
+            RING_STAMP(1);                                          // LDS reads of the first row (the stamp waits for them)
+            step(std::integral_constant<int, U>{}, ra, S0, ts0);
+            RING_STAMP(2);
+            {
+                RowRegs<D, WS> rb;
+                lds_row(sl_cur, rb);
+                RING_STAMP(3);
+                step(std::integral_constant<int, U + 1>{}, rb, S1, ts1);
+            }
+            RING_STAMP(4);
+#if RING_PRELOAD
+            if (t + 2 < nsteps2) lds_row(sl_cur, ra);               // the next pair's first row: in flight during the selection
+#endif
+            if (t < WS - 1) return true;                            // the window is still filling (WS - 1 is even)
+            // lanes l and l+32 hold the two halves of a pixel for rows t (S0) and t+1 (S1): after the swap the lower lane
+            // has both halves of row t and the upper lane both halves of row t+1
+            uint32_t rr[D / 2];
+#pragma unroll
+            for (int i = 0; i < NRL; ++i) {
+#if RING_ABL == 5 || RING_ABL == 6
+                rr[i] = S0[i]; rr[NRL + i] = S1[i];
+#else
+                const auto sw = __builtin_amdgcn_permlane32_swap(S0[i], S1[i], false, false);
+                rr[i] = sw[0]; rr[NRL + i] = sw[1];
+#endif
+            }
+            RING_STAMP(5);                                          // swaps
+            const int tsum = h ? ts1 : ts0;
+            const int y = ys0 + (t - (WS - 1)) + h;
+            const bool row_ok = y < ys1;
+            // Selection is skipped for a wave none of whose pixels can produce a disparity here (untextured, outside the
+            // tile, masked): exact, such a pixel is FILTERED and writes no cost whatever its SADs are.
+            const bool dead = !active || !row_ok || masked_col || tsum < g.tex;
+            if (__builtin_amdgcn_ballot_w64(!dead) == 0) {
+                if (active && row_ok) db[(size_t)y * disp.pitch_e + col] = (int16_t)g.filtered;
+            } else {
+                int m1; bool fail;
+#if RING_ABL == 1 || RING_ABL == 6
+                uint32_t xo = 0;
+#pragma unroll
+                for (int i = 0; i < D / 2; ++i) xo ^= rr[i];
+                const int out = (int)xo; m1 = (int)(xo >> 3); fail = (xo & 1) != 0;
+#elif RING_LDS_SELECT
+                const int out = select_disparity_lds<D>(rr, tsum, g, scr, &m1, &fail);
+#else
+                const int out = select_disparity<D>(rr, tsum, g, &m1, &fail);
+#endif
+#if RING_ABL == 2
+                if (active && row_ok && out == 0x12345678) {
+#else
+                if (active && row_ok) {
+#endif
+                    if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)m1;
+                    db[(size_t)y * disp.pitch_e + col] = (int16_t)(masked_col ? g.filtered : out);
+                }
+            }
+            RING_STAMP(6);                                          // selection + stores
+            return true;
+        });
+    }
+#ifdef RING_STAMPS
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&ring_stamps[i], stamp_sum[i]);
+#endif
+}
+
+// ---- host side ----------------------------------------------------------------------------
+static bool ring_range(const BMGeom& g, int* x0, int* nx)
+{
+    const int r = g.r;
+    int xl = 0, xh = g.width1 - 1;
+    xl = max(xl, r - g.lofs); xl = max(xl, r - g.rofs);
+    xh = min(xh, g.W - 1 - g.lofs - r); xh = min(xh, g.W - g.D - g.rofs - r);
+    xl = max(xl, g.cx0 - g.lofs); xh = min(xh, g.cx1 - g.lofs - 1);      // setROI1: only the needed columns
+    if (x0) *x0 = xl;
+    if (nx) *nx = xh - xl + 1;
+    return xh >= xl;
+}
+
+// rows a strip may have so that no prefix sum leaves 16 bits: a row adds at most w * 2 cap per disparity, and a strip of
+// rs output rows walks rs + w - 1 rows plus one padded row
+static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g.w; }
+
+int ring_strips_model(const BMGeom& g, int n)
+{
+    int x0 = 0, nx = 0;
+    if (!ring_range(g, &x0, &nx)) return 1;
+    const int tiles = (nx + 127) / 128, nrows = g.vy1 - g.vy0;
+    // 2 workgroups per CU resident => 512 slots; a strip pays w-1 filling rows at about half the price of an output row
+    int s = (int)(sqrtf((float)nrows * 512.0f / (0.5f * (float)(g.w - 1) * (float)tiles * (float)n)) + 0.5f);
+    s = max(s, (nrows + ring_rows_cap(g) - 1) / ring_rows_cap(g));
+    return max(1, min(s, (nrows + 15) / 16));
+}
+
+template <int D, int WS>
+static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint)
+{
+    using C = RingCfg<D, WS>;
+    RingGeom rg;
+    ring_range(g, &rg.x0, &rg.nx);
+    const int rem = g.w - 4 * (C::NP - 1);
+    rg.lastmask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
+    const int nrows = g.vy1 - g.vy0;
+    const int tiles = (rg.nx + C::TILE - 1) / C::TILE;
+    int strips = strips_hint > 0 ? strips_hint : ring_strips_model(g, n);
+    const int cap = ring_rows_cap(g);
+    strips = max(strips, (nrows + cap - 1) / cap);
+    strips = max(1, min(strips, nrows));
+    rg.rs = (nrows + strips - 1) / strips;
+    strips = (nrows + rg.rs - 1) / rg.rs;
+    rg.tiles = tiles; rg.strips = strips;
+    rg.nitems = (unsigned)tiles * strips * n;
+    const size_t ldsb = (size_t)4 * C::WAVE_LDS * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set && ldsb > 48 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_search_ring<D, WS>), dim3(rg.nitems), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg);
+}
+
+// Instantiations: (D, blockSize) whose ring (blockSize+1) * D/4 registers per lane leaves room for two waves per SIMD.
+#define RTDM_RING_TABLE(X) X(64, 9)
+
+bool ring_search_supported(const BMGeom& g)
+{
+    static const bool off = [] { const char* e = getenv("RTDM_RING"); return e && atoi(e) == 0; }();   // A/B switch
+    if (off) return false;
+    if (2L * g.cap * g.w * g.w > 32766) return false;       // packed u16 sums + the T+1 <= 32767 argument of the selection
+    if (ring_rows_cap(g) < 2) return false;
+    if (!ring_range(g, nullptr, nullptr)) return false;
+#define X(DD, WW) if (g.D == DD && g.w == WW) return true;
+    RTDM_RING_TABLE(X)
+#undef X
+    return false;
+}
+
+void launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint)
+{
+#define X(DD, WW) if (g.D == DD && g.w == WW) { ring_launch_one<DD, WW>(Lp, Rp, disp, cost, g, n, stream, strips_hint); return; }
+    RTDM_RING_TABLE(X)
+#undef X
+}
+
+}  // namespace rtdm

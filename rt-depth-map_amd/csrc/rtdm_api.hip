@@ -304,19 +304,23 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
 // counts, not positions): a caller that moves a same-sized ROI around (estimator.cpp:53-54) keeps its entry.  A shape is
 // measured the SECOND time it is seen -- a caller whose ROI changes size every call never pays the ~30 extra launches and
 // the stream synchronisation -- and the table is a 16-entry LRU.  Small batches keep the model.  RTDM_AUTOTUNE=0: off.
-static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plane16W disp, const BMGeom& g, int n, hipStream_t s, bool fuse)
+static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plane16W disp, const BMGeom& g, int n, hipStream_t s, bool fuse, bool ring)
 {
+    const auto launch = [&](int c) {
+        if (ring) launch_search_ring(Lpr, Rpr, disp, ln.dCost, g, n, s, c);
+        else launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);
+    };
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("RTDM_AUTOTUNE"); enabled = e ? atoi(e) : 1; }
     if (!enabled || n < 16 || getenv("RTDM_FAST_WGS")) return 0;
-    TuneKey key{g.W, g.H, n, g.cx1 - g.cx0, g.vy1 - g.vy0, fuse ? 1 : 0};
+    TuneKey key{g.W, g.H, n, g.cx1 - g.cx0, g.vy1 - g.vy0, (fuse ? 1 : 0) | (ring ? 2 : 0)};
     for (size_t i = 0; i < bm->tuned.size(); ++i) {
         if (!(bm->tuned[i].key == key)) continue;
         TuneEntry e = bm->tuned[i];
         bm->tuned.erase(bm->tuned.begin() + (long)i);              // most recently used goes to the back
         if (e.strips == 0) {
             e.strips = -1;                                          // being measured: a failure below leaves the model in charge
-            const int model = fast_strips_model(g, n), cap = (g.vy1 - g.vy0 + 15) / 16;
+            const int model = ring ? ring_strips_model(g, n) : fast_strips_model(g, n), cap = (g.vy1 - g.vy0 + 15) / 16;
             int best = model;
             float best_ms = 1e30f;
             hipEvent_t a, b;
@@ -330,11 +334,11 @@ static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plan
                         for (int k = 0; k < nseen; ++k) dup |= seen[k] == c;
                         if (dup) continue;
                         seen[nseen++] = c;
-                        launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);          // warm
+                        launch(c);          // warm
                         float ms = 1e30f;
                         for (int rep = 0; rep < 2; ++rep) {
                             (void)hipEventRecord(a, s);
-                            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);
+                            launch(c);
                             (void)hipEventRecord(b, s);
                             float t = 0.f;
                             if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&t, a, b) == hipSuccess) ms = std::min(ms, t);
@@ -390,7 +394,8 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
     bool u16 = false;
     if (!generic_search_supported(g, &u16)) return RTDM_ERR_UNSUPPORTED;
     {
-        bm->variant = fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
+        const bool ring = fast && ring_search_supported(g);
+        bm->variant = ring ? "fast_ring_qsad" : fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
         Plane8W Lp{ln.dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{ln.dRp, bm->ppitch, bm->ppitch * (size_t)H};
         stage_begin(bm, RTDM_STAGE_PREFILTER, n, s, &ev);
         launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s);
@@ -407,16 +412,17 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
             // (search -2 %).  Single frames keep the fused launch (one kernel less).  RTDM_BORDER_ASYNC=0: always fused.
             static const bool async_border = [] { const char* e = getenv("RTDM_BORDER_ASYNC"); return !e || atoi(e) != 0; }();
             const bool side = async_border && border_search_supported(g) && n >= 16;
-            const bool fuse = border_search_supported(g) && !separate && !side;
+            const bool fuse = border_search_supported(g) && !separate && !side && !ring;   // the ring kernel's grid has tiles only
             // (measured, if at all, before the side stream forks: nothing else runs beside the timed launches)
-            const int strips = tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse);
+            const int strips = tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse, ring);
             if (side) {
                 HIPC(hipEventRecord(ln.fork, s));
                 HIPC(hipStreamWaitEvent(ln.side, ln.fork, 0));
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, ln.side, lx0, lx1, rx0, rx1);
                 HIPC(hipEventRecord(ln.join, ln.side));
             }
-            launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, strips);
+            if (ring) launch_search_ring(Lpr, Rpr, disp, ln.dCost, g, n, s, strips);
+            else launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, strips);
             if (side) {
                 HIPC(hipStreamWaitEvent(s, ln.join, 0));
             } else if (fuse) {

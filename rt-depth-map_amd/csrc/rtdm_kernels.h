@@ -54,6 +54,13 @@ bool fast_search_supported(const BMGeom& g);
 void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g,
                         int n, hipStream_t stream, bool fuse_border, int strips_hint = 0);
 int fast_strips_model(const BMGeom& g, int n);
+// K2 (ring variant, k_search_ring.hip): the same columns as the fast variant, prefix sums in a register ring instead of a
+// leaving-row recomputation; covers the (D, blockSize) pairs whose ring fits two waves per SIMD.  Border columns always go
+// to launch_search_border.  ring_search_supported implies fast_search_supported's column range.
+bool ring_search_supported(const BMGeom& g);
+void launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream,
+                        int strips_hint = 0);
+int ring_strips_model(const BMGeom& g, int n);
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
 // wave-per-column kernel for those border columns (falls back to the generic kernel if unsupported)
 bool border_search_supported(const BMGeom& g);

@@ -1,0 +1,237 @@
+// rtdm_select.h -- per-pixel selection of the SAD search, all in registers (oracle:
+// oracle/bm_oracle.c:175-191): given the D window SADs of one pixel as packed u16 pairs -- rr[i] holds sad[2i] (low
+// half) and sad[2i+1] (high half), index = REVERSED disparity -- produce
+//   (minsad, FIRST argmin)            ties => the smallest index = the largest disparity
+//   texture / uniqueness rejection    any index outside [a-1, a+1] with sad <= minsad + minsad*ratio/100 => FILTERED
+//   sub-pixel disparity x16           ((D-a-1+minD)*256 + (p-n)*256/den + 15) >> 4, truncating division
+// Lane = pixel; the 64 lanes of the wave must all call it (it uses wave-wide votes to skip work).
+//
+// Two levels: packed minima of groups of four registers (eight disparities; v_pk_min_u16 serves two values per
+// instruction and needs no key), 32-bit keys (min << 8 | group) built by v_perm and reduced with v_min3_u32 give
+// (minsad, first group), the six registers around that group come out of a v_cndmask tree and the eight in-group keys
+// (sad << 8 | e) give the FIRST argmin; uniqueness is the identity
+//     sum_e max(T+1 - sad[e], 0)  ==  the same sum over {a-1, a, a+1}
+// evaluated with saturating packed u16 ops (groups above the threshold in the whole wave are skipped);
+// sad[a +- 1] are among the six fetched registers.  Needs every sad <= 32766.
+#pragma once
+
+#include "rtdm_kernels.h"
+
+namespace rtdm {
+
+typedef unsigned short sel_us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t sel_pk_min(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(sel_us2, a), __builtin_bit_cast(sel_us2, b))); }
+__device__ __forceinline__ uint32_t sel_pk_sub_sat(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(sel_us2, a), __builtin_bit_cast(sel_us2, b))); }
+__device__ __forceinline__ uint32_t sel_pk_add_sat(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(sel_us2, a), __builtin_bit_cast(sel_us2, b))); }
+
+__device__ __forceinline__ int sel_div_trunc(int num, int den)   // den > 0, |num| < 2^24
+{
+    const unsigned an = (unsigned)(num < 0 ? -num : num);
+    unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
+    int rem = (int)an - (int)(q * (unsigned)den);
+    if (rem < 0) { --q; rem += den; }
+    if (rem < 0) { --q; rem += den; }
+    if (rem >= den) { ++q; rem -= den; }
+    if (rem >= den) { ++q; }
+    return num < 0 ? -(int)q : (int)q;
+}
+
+// Returns the x16 disparity (g.filtered if rejected); *minsad = the winning SAD, *rejected = the pixel failed a test.
+template <int D>
+__device__ __forceinline__ int select_disparity(const uint32_t (&rr)[D / 2], int tsum, const BMGeom& g, int* minsad, bool* rejected)
+{
+    constexpr int NR = D / 2, NGp = NR / 4;
+    uint32_t kacc[2] = {0xffffffffu, 0xffffffffu};   // two chains: no back-to-back dependency
+    uint32_t gmin[NGp];                               // kept: the uniqueness test skips groups above its threshold
+#pragma unroll
+    for (int gq = 0; gq < NGp; ++gq) {
+        const uint32_t gm = sel_pk_min(sel_pk_min(rr[4 * gq], rr[4 * gq + 1]), sel_pk_min(rr[4 * gq + 2], rr[4 * gq + 3]));
+        gmin[gq] = gm;
+        const uint32_t gc = (uint32_t)gq | ((uint32_t)gq << 8);
+        const uint32_t klo = __builtin_amdgcn_perm(gm, gc, 0x0C050400u);
+        const uint32_t khi = __builtin_amdgcn_perm(gm, gc, 0x0C070601u);
+        kacc[gq & 1] = min(min(kacc[gq & 1], klo), khi);
+    }
+    const uint32_t kmin = min(kacc[0], kacc[1]);
+    const int m1 = (int)(kmin >> 8);
+    const int gs = (int)(kmin & 0xffu);
+    // six[k] = rr[4 gs - 1 + k], k = 0..5 (0 outside the array): binary select on the bits of gs
+    uint32_t six[6];
+    {
+        uint32_t cand[6][NGp];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int gq = 0; gq < NGp; ++gq) {
+                const int idx = 4 * gq - 1 + k;
+                cand[k][gq] = (idx >= 0 && idx < NR) ? rr[idx] : 0u;
+            }
+        constexpr int HBG = (NGp - 1) >= 16 ? 16 : (NGp - 1) >= 8 ? 8 : (NGp - 1) >= 4 ? 4 : (NGp - 1) >= 2 ? 2 : 1;
+        int len = NGp;
+#pragma unroll
+        for (int bit = HBG; bit >= 1; bit >>= 1) {
+            const bool up = (gs & bit) != 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+#pragma unroll
+                for (int i = 0; i < bit; ++i)
+                    if (i < len) cand[k][i] = up ? ((i + bit < len) ? cand[k][i + bit] : 0u) : cand[k][i];
+            len = bit < len ? bit : len;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) six[k] = cand[k][0];
+    }
+    uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
+        const uint32_t klo = __builtin_amdgcn_perm(six[1 + q], ec, 0x0C050400u);
+        const uint32_t khi = __builtin_amdgcn_perm(six[1 + q], ec, 0x0C070601u);
+        k3[q & 1] = min(min(k3[q & 1], klo), khi);
+    }
+    const int a = 8 * gs + (int)(min(k3[0], k3[1]) & 0xffu);
+    // the two packed registers that hold sad[a-1 .. a+1] are among the six
+    const int am1 = a > 0 ? a - 1 : 0;
+    const int jl = (am1 >> 1) - (4 * gs - 1);                 // 0..4
+    const bool j1 = (jl & 1) != 0, j2 = (jl & 2) != 0, j4 = (jl & 4) != 0;
+    const uint32_t e0 = j4 ? six[4] : (j2 ? (j1 ? six[3] : six[2]) : (j1 ? six[1] : six[0]));
+    const uint32_t e1 = j4 ? six[5] : (j2 ? (j1 ? six[4] : six[3]) : (j1 ? six[2] : six[1]));
+    const int posc = a > 0 ? (am1 & 1) + 1 : 0;         // position of sad[a] among the 4 fetched
+    const auto elem = [&](int pos) -> int {
+        return (int)__builtin_amdgcn_perm(e1, e0, 0x0C0C0100u + 0x0202u * (uint32_t)pos);
+    };
+    const bool has_n = a > 0, has_p = a + 1 < D;
+    const int n_real = elem(has_n ? posc - 1 : 0);
+    const int p_real = elem(has_p ? posc + 1 : 0);
+    bool fail = tsum < g.tex;
+    if (g.uniq > 0) {
+        uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
+        T = min(T, 32766u);
+        const uint32_t T1 = T + 1u, T1pk = T1 * 0x00010001u;
+        // saturating sums of non-negative terms are order independent: four chains
+        // (the empty asm pins "four subtractions, then four additions": back-to-back dependent
+        //  packed ops cost a wait state each on gfx950)
+        uint32_t zz[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NR; i += 4) {
+            // a group none of whose eight values reaches the threshold in any lane adds nothing (exact)
+            if (__builtin_amdgcn_ballot_w64(sel_pk_sub_sat(T1pk, gmin[i >> 2]) != 0u) == 0) continue;
+            uint32_t t0 = sel_pk_sub_sat(T1pk, rr[i]), t1 = sel_pk_sub_sat(T1pk, rr[i + 1]);
+            uint32_t t2 = sel_pk_sub_sat(T1pk, rr[i + 2]), t3 = sel_pk_sub_sat(T1pk, rr[i + 3]);
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+            zz[0] = sel_pk_add_sat(zz[0], t0); zz[1] = sel_pk_add_sat(zz[1], t1);
+            zz[2] = sel_pk_add_sat(zz[2], t2); zz[3] = sel_pk_add_sat(zz[3], t3);
+        }
+        const uint32_t z = sel_pk_add_sat(sel_pk_add_sat(zz[0], zz[1]), sel_pk_add_sat(zz[2], zz[3]));
+        const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
+        const uint32_t wsame = term(m1);
+        const uint32_t wother = (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
+        const uint32_t zlo = z & 0xffffu, zhi = z >> 16;
+        const bool even = (a & 1) == 0;
+        fail |= (even ? zlo : zhi) != wsame;
+        fail |= (even ? zhi : zlo) != wother;
+    }
+    int out = g.filtered;
+    if (!fail) {
+        const int pp = has_p ? p_real : n_real;
+        const int nn = has_n ? n_real : p_real;
+        const int den = pp + nn - 2 * m1 + abs(pp - nn);
+        const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
+        out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
+    }
+    *minsad = m1;
+    *rejected = fail;
+    return out;
+}
+
+// The same selection with the data-dependent register fetches done through LDS: the D values are written once to the
+// lane's scratch record (conflict-free 16-byte stores at a 144-byte lane stride), the winning group comes back with ONE
+// 16-byte read and sad[a-1], sad[a+1] with two 2-byte reads -- in place of the 42 + 14 v_cndmask of the register tree --
+// and both round trips are in flight while the uniqueness sum (which needs only minsad) is computed.
+// scr: this LANE's record, SEL_LANE_DWORDS dwords apart from its neighbours', 16-byte aligned; private to the wave.
+constexpr int SEL_LANE_DWORDS = 36;
+template <int D>
+__device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2], int tsum, const BMGeom& g, uint32_t* scr,
+                                                    int* minsad, bool* rejected)
+{
+    constexpr int NR = D / 2, NGp = NR / 4;
+    static_assert(NR <= SEL_LANE_DWORDS - 4, "record too small");
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < NR; i += 4) *(u4*)(scr + i) = u4{rr[i], rr[i + 1], rr[i + 2], rr[i + 3]};
+    uint32_t kacc[2] = {0xffffffffu, 0xffffffffu};
+    uint32_t gmin[NGp];
+#pragma unroll
+    for (int gq = 0; gq < NGp; ++gq) {
+        const uint32_t gm = sel_pk_min(sel_pk_min(rr[4 * gq], rr[4 * gq + 1]), sel_pk_min(rr[4 * gq + 2], rr[4 * gq + 3]));
+        gmin[gq] = gm;
+        const uint32_t gc = (uint32_t)gq | ((uint32_t)gq << 8);
+        const uint32_t klo = __builtin_amdgcn_perm(gm, gc, 0x0C050400u);
+        const uint32_t khi = __builtin_amdgcn_perm(gm, gc, 0x0C070601u);
+        kacc[gq & 1] = min(min(kacc[gq & 1], klo), khi);
+    }
+    const uint32_t kmin = min(kacc[0], kacc[1]);
+    const int m1 = (int)(kmin >> 8);
+    const int gs = (int)(kmin & 0xffu);
+    const u4 grp = *(const u4*)(scr + 4 * gs);                  // the four registers of the winning group
+    // uniqueness: sum_e max(T+1 - sad[e], 0) over ALL e, compared below with the same sum over {a-1, a, a+1}
+    uint32_t z = 0;
+    uint32_t T1 = 0;
+    if (g.uniq > 0) {
+        uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
+        T = min(T, 32766u);
+        T1 = T + 1u;
+        const uint32_t T1pk = T1 * 0x00010001u;
+        uint32_t zz[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NR; i += 4) {
+            // a group none of whose eight values reaches the threshold in any lane adds nothing (exact)
+            if (__builtin_amdgcn_ballot_w64(sel_pk_sub_sat(T1pk, gmin[i >> 2]) != 0u) == 0) continue;
+            uint32_t t0 = sel_pk_sub_sat(T1pk, rr[i]), t1 = sel_pk_sub_sat(T1pk, rr[i + 1]);
+            uint32_t t2 = sel_pk_sub_sat(T1pk, rr[i + 2]), t3 = sel_pk_sub_sat(T1pk, rr[i + 3]);
+            asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+            zz[0] = sel_pk_add_sat(zz[0], t0); zz[1] = sel_pk_add_sat(zz[1], t1);
+            zz[2] = sel_pk_add_sat(zz[2], t2); zz[3] = sel_pk_add_sat(zz[3], t3);
+        }
+        const uint32_t zp = sel_pk_add_sat(sel_pk_add_sat(zz[0], zz[1]), sel_pk_add_sat(zz[2], zz[3]));
+        // both halves saturate at 65535, above anything the three-term sum of a parity can reach: the total stays >= the
+        // expected total, with equality only if no half saturated and nothing outside {a-1, a, a+1} contributed
+        z = (zp & 0xffffu) + (zp >> 16);
+    }
+    uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
+        const uint32_t klo = __builtin_amdgcn_perm(grp[q], ec, 0x0C050400u);
+        const uint32_t khi = __builtin_amdgcn_perm(grp[q], ec, 0x0C070601u);
+        k3[q & 1] = min(min(k3[q & 1], klo), khi);
+    }
+    const int a = 8 * gs + (int)(min(k3[0], k3[1]) & 0xffu);
+    const bool has_n = a > 0, has_p = a + 1 < D;
+    const unsigned short* sv = (const unsigned short*)scr;
+    const int n_real = sv[has_n ? a - 1 : a];
+    const int p_real = sv[has_p ? a + 1 : a];
+    bool fail = tsum < g.tex;
+    if (g.uniq > 0) {
+        const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
+        const uint32_t want = term(m1) + (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
+        fail |= z != want;
+    }
+    int out = g.filtered;
+    if (!fail) {
+        const int pp = has_p ? p_real : n_real;
+        const int nn = has_n ? n_real : p_real;
+        const int den = pp + nn - 2 * m1 + abs(pp - nn);
+        const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
+        out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
+    }
+    *minsad = m1;
+    *rejected = fail;
+    return out;
+}
+
+}  // namespace rtdm
