@@ -71,6 +71,7 @@ def lib():
         "rtdm_bm_get_stage_time": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "rtdm_bm_reset_stage_times": (C.c_int, [vp]),
         "rtdm_bm_search_variant": (C.c_char_p, [vp]),
+        "rtdm_debug_search_kernel": (None, [C.c_int]),
         "rtdm_morph_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
         "rtdm_morph_destroy": (None, [vp]),
         "rtdm_morph_in_buffer": (vp, [vp]),
@@ -114,7 +115,7 @@ def lib():
 EXPORTS = ("rtdm_strerror rtdm_last_hip_error rtdm_abi_version rtdm_device_count rtdm_bm_default_params "
            "rtdm_bm_create rtdm_bm_destroy rtdm_bm_set_roi rtdm_bm_get_params rtdm_bm_compute "
            "rtdm_bm_compute_device rtdm_bm_compute_batch rtdm_bm_synchronize rtdm_bm_set_profiling "
-           "rtdm_bm_get_stage_time rtdm_bm_reset_stage_times rtdm_bm_search_variant rtdm_morph_create "
+           "rtdm_bm_get_stage_time rtdm_bm_reset_stage_times rtdm_bm_search_variant rtdm_debug_search_kernel rtdm_morph_create "
            "rtdm_morph_destroy rtdm_morph_in_buffer rtdm_morph_out_buffer rtdm_morph_run "
            "rtdm_morph_run_device rtdm_synth_pairs_device rtdm_sgm_default_params rtdm_sgm_create rtdm_sgm_destroy "
            "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_bm_compute_depth rtdm_depth_stats_device "

@@ -81,7 +81,10 @@ struct RingCfg {
     static constexpr int SLOT = ITEMS * 64;        // padded: every lane stores every item, no exec masking
     static constexpr int NSLOT = 3;                // staged rows in flight per wave
     static constexpr int STG = (NSLOT * SLOT + W1 * 64 + 3) & ~3;   // dwords per wave: staged rows + the texture prefix ring
-    static constexpr int WAVE_LDS = STG + 64 * SEL_LANE_DWORDS;     // + the selection's per-lane records (rtdm_select.h)
+    static constexpr int WAVE_LDS = STG + 64 * SelRecord<D>::DWORDS;   // + the selection's per-lane records (rtdm_select.h)
+    // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
+    static constexpr int RING_REGS = W1 * NRL;
+    static constexpr int WAVES = RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
     static constexpr int TILE = 128;
 };
 
@@ -169,7 +172,7 @@ __device__ __forceinline__ void ring_for_pairs(std::integer_sequence<int, U...>,
 { (void)(f(std::integral_constant<int, U>{}) && ...); }
 
 template <int D, int WS>
-__global__ __launch_bounds__(256, 2) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg)
+__global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg)
 {
     using C = RingCfg<D, WS>;
     constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS;
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void k_search_ring(Plane8 Lp, Plane8 Rp, Pl
     uint32_t* stg = lds + phi * C::WAVE_LDS;       // this wave's slice: nothing below is shared between waves
     uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][64]
 #if RING_LDS_SELECT
-    uint32_t* scr = stg + C::STG + lane * SEL_LANE_DWORDS;   // this lane's selection record
+    uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;   // this lane's selection record
 #endif
 
     // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
@@ -429,7 +432,8 @@ static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
     strips = (nrows + rg.rs - 1) / rg.rs;
     rg.tiles = tiles; rg.strips = strips;
     rg.nitems = (unsigned)tiles * strips * n;
-    const size_t ldsb = (size_t)4 * C::WAVE_LDS * sizeof(uint32_t);
+    static const size_t ldspad = [] { const char* e = getenv("RTDM_RING_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const size_t ldsb = (size_t)4 * C::WAVE_LDS * sizeof(uint32_t) + ldspad;   // (padding: occupancy experiments)
     static bool attr_set = false;
     if (!attr_set && ldsb > 48 * 1024) {
         (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
@@ -439,12 +443,16 @@ static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
 }
 
 // Instantiations: (D, blockSize) whose ring (blockSize+1) * D/4 registers per lane leaves room for two waves per SIMD.
-#define RTDM_RING_TABLE(X) X(64, 9)
+#define RTDM_RING_TABLE(X) X(64, 9) X(64, 7) X(64, 5) X(32, 7) X(32, 9) X(32, 11) X(32, 13) X(48, 7) X(48, 9) X(16, 5) X(16, 7) X(16, 9)
+
+static int g_ring_mode = -1;            // rtdm_debug_search_kernel: 0 never, 1 wherever instantiated, -1 default
+void ring_set_mode(int mode) { g_ring_mode = mode; }
 
 bool ring_search_supported(const BMGeom& g)
 {
-    static const bool off = [] { const char* e = getenv("RTDM_RING"); return e && atoi(e) == 0; }();   // A/B switch
-    if (off) return false;
+    static const int env = [] { const char* e = getenv("RTDM_RING"); return e ? atoi(e) : -1; }();   // A/B switch
+    const int mode = g_ring_mode >= 0 ? g_ring_mode : env;
+    if (mode == 0) return false;
     if (2L * g.cap * g.w * g.w > 32766) return false;       // packed u16 sums + the T+1 <= 32767 argument of the selection
     if (ring_rows_cap(g) < 2) return false;
     if (!ring_range(g, nullptr, nullptr)) return false;

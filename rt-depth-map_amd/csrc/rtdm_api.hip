@@ -633,6 +633,7 @@ int rtdm_bm_reset_stage_times(rtdm_bm* bm)
 }
 
 const char* rtdm_bm_search_variant(const rtdm_bm* bm) { return bm ? bm->variant.c_str() : ""; }
+void rtdm_debug_search_kernel(int mode) { ring_set_mode(mode); }
 
 // ---- VideoFilterDevice ---------------------------------------------------------------------
 int rtdm_morph_create(int width, int height, int max_batch, int device, rtdm_morph** out)

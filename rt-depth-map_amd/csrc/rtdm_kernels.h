@@ -61,6 +61,7 @@ bool ring_search_supported(const BMGeom& g);
 void launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream,
                         int strips_hint = 0);
 int ring_strips_model(const BMGeom& g, int n);
+void ring_set_mode(int mode);   // rtdm_debug_search_kernel
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
 // wave-per-column kernel for those border columns (falls back to the generic kernel if unsupported)
 bool border_search_supported(const BMGeom& g);

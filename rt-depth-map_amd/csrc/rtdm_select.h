@@ -152,14 +152,15 @@ __device__ __forceinline__ int select_disparity(const uint32_t (&rr)[D / 2], int
 // lane's scratch record (conflict-free 16-byte stores at a 144-byte lane stride), the winning group comes back with ONE
 // 16-byte read and sad[a-1], sad[a+1] with two 2-byte reads -- in place of the 42 + 14 v_cndmask of the register tree --
 // and both round trips are in flight while the uniqueness sum (which needs only minsad) is computed.
-// scr: this LANE's record, SEL_LANE_DWORDS dwords apart from its neighbours', 16-byte aligned; private to the wave.
-constexpr int SEL_LANE_DWORDS = 36;
+// scr: this LANE's record, SelRecord<D>::DWORDS dwords apart from its neighbours', 16-byte aligned; private to the wave.
+template <int D> struct SelRecord { static constexpr int DWORDS = D / 2 + 4; };   // 12, 20, 28, 36: eight consecutive lanes' 16-byte
+                                                                                  // stores start in eight different bank quads
 template <int D>
 __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2], int tsum, const BMGeom& g, uint32_t* scr,
                                                     int* minsad, bool* rejected)
 {
     constexpr int NR = D / 2, NGp = NR / 4;
-    static_assert(NR <= SEL_LANE_DWORDS - 4, "record too small");
+    static_assert(D == 16 || D == 32 || D == 48 || D == 64, "record stride checked for these sizes only");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int i = 0; i < NR; i += 4) *(u4*)(scr + i) = u4{rr[i], rr[i + 1], rr[i + 2], rr[i + 3]};

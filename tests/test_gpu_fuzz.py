@@ -96,11 +96,45 @@ def test_every_fast_instantiation(pkg, oracle, synth, D, pieces):
     W, H = D + 4 * w + 150, w + 37
     L, R = synth.make_pair(synth.STREAM_SEED + 9000 + D + pieces, W, H, D)
     kw = dict(numDisparities=D, blockSize=w, preFilterCap=31 if 62 * w * w <= 32766 else 15)
-    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, preFilterCap=kw["preFilterCap"], width=W, height=H)
-    got = m.compute(L, R)
-    assert m.search_variant == "fast_qsad", (D, w, m.search_variant)
-    m.close()
+    pkg.binding.lib().rtdm_debug_search_kernel(0)          # this test is about k_search_fast
+    try:
+        m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, preFilterCap=kw["preFilterCap"], width=W, height=H)
+        got = m.compute(L, R)
+        assert m.search_variant == "fast_qsad", (D, w, m.search_variant)
+        m.close()
+    finally:
+        pkg.binding.lib().rtdm_debug_search_kernel(-1)
     assert np.array_equal(got, oracle.bm_compute(L, R, **kw)), (D, w)
+
+
+RING_TABLE = [(64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9)]
+
+
+@pytest.mark.parametrize("D,w", RING_TABLE)
+def test_every_ring_instantiation(pkg, oracle, synth, D, w):
+    # k_search_ring (prefix sums in a register ring): odd and even row counts, a strip boundary inside the frame (rows >
+    # the 16-bit cap of a strip at cap 63), ROI, negative and positive minDisparity, thresholds off
+    pkg.binding.lib().rtdm_debug_search_kernel(1)
+    try:
+        for k, (W, H, kw) in enumerate([
+                (D + 4 * w + 150, w + 37, {}),
+                (D + 300, 2 * w + 120, dict(preFilterCap=63 if 126 * w * w <= 32766 else 31)),
+                (D + 260, w + 46, dict(minDisparity=-3, uniquenessRatio=0, textureThreshold=0)),
+                (D + 333, w + 51, dict(minDisparity=5, disp12MaxDiff=-1, speckleWindowSize=0)),
+                (D + 400, 131, dict(roi1=(D + 20, 9, 250, 90)))]):
+            L, R = synth.make_pair(synth.STREAM_SEED + 9500 + D + w + k, W, H, D)
+            roi1 = kw.pop("roi1", None)
+            m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, **kw)
+            if roi1: m.setROI1(roi1)
+            got = m.compute(L, R)
+            assert m.search_variant == "fast_ring_qsad", (D, w, m.search_variant)
+            m.close()
+            okw = dict(kw); okw.update(numDisparities=D, blockSize=w)
+            if roi1: okw["roi1"] = roi1
+            want = oracle.bm_compute(L, R, **okw)
+            assert np.array_equal(got, want), (D, w, k, int((got != want).sum()))
+    finally:
+        pkg.binding.lib().rtdm_debug_search_kernel(-1)
 
 
 @pytest.mark.parametrize("W,H,D,w", [(4096, 48, 64, 9), (4095, 31, 128, 11), (90, 700, 64, 9), (70, 10, 64, 9), (25, 25, 16, 5),
