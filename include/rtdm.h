@@ -129,24 +129,28 @@ int rtdm_morph_run_device(rtdm_morph* mf, int n, const uint8_t* d_in, size_t in_
                           size_t in_frame_stride, uint8_t* d_out, size_t out_pitch,
                           size_t out_frame_stride, int width, int height, void* hip_stream);
 
-/* ---- SWSemiGlobalMatcher counterpart: SGM with 8-path aggregation (BASELINE config 5) --------
+/* ---- SWSemiGlobalMatcher counterpart: cv::StereoSGBM (rows S / f4, BASELINE config 5) -------------------
  * rtdm_sgm_create   <- SWSemiGlobalMatcher::SWSemiGlobalMatcher (stereo-matcher/sgbm-sw.cpp:12-25):
  *                      StereoSGBM::create(0, numDisparities, blockSize), P1 = 600, P2 = 2400 (:17-18),
- *                      then the five setters (:19-24).  preFilterCap stays 0 (=> clip at +-15).
+ *                      then the five setters (:19-24).  preFilterCap stays 0 (=> clip at +-15), mode MODE_SGBM.
  * rtdm_sgm_compute  <- SWSemiGlobalMatcher::compute (sgbm-sw.cpp:32-37); setROI1/2 are no-ops in the
  *                      reference (sgbm-sw.h:32-33), so there is no ROI entry point.
- * The algorithm is the 8-direction variant defined by oracle/sgm_oracle.c (integer arithmetic). */
+ * The algorithm is the restatement of cv::StereoSGBM::compute in oracle/sgm_oracle.c (rules R1-R12 there: pixel cost,
+ * block sum, 5 or 8 path directions, saturating sum, winner / uniqueness / sub-pixel, the always-on left-right check,
+ * 3x3 median, speckle filter), integer arithmetic, bit-exact against that oracle; parity against the library itself is
+ * unpinned (OpenCV is not available where this was built). */
 typedef struct rtdm_sgm_params {
-    int blockSize;         /* odd >= 1 */
+    int blockSize;         /* odd >= 1; 93 * blockSize^2 + P2 must stay <= 32767 (<= 17 at P2 = 2400): beyond that the
+                            * library's 16-bit costs wrap around, which is not reproduced (RTDM_ERR_UNSUPPORTED) */
     int minDisparity;
     int numDisparities;    /* multiple of 16, <= 256 */
-    int P1, P2;            /* 0 < P1 < P2 */
-    int uniquenessRatio;   /* 0..100 */
-    int speckleWindowSize; /* <= 0 disables */
+    int P1, P2;            /* as the library: P1 <= 0 -> 2, P2 <= 0 -> 5, P2 >= P1 + 1 */
+    int uniquenessRatio;   /* <= 100; < 0 -> 10 */
+    int speckleWindowSize; /* <= 0 disables the speckle filter */
     int speckleRange;      /* multiplied by 16, as cv::StereoSGBM does */
-    int disp12MaxDiff;     /* < 0 disables */
-    int paths;             /* 8 (BASELINE config 5) or 5: the directions of cv::StereoSGBM's default MODE_SGBM, which is the
-                            * mode sgbm-sw.cpp:15 creates (left, right, down, down-right, down-left) */
+    int disp12MaxDiff;     /* <= 0 -> 1: the library's left-right check cannot be switched off */
+    int paths;             /* 5: MODE_SGBM, the mode sgbm-sw.cpp:15 creates (left, right, down, down-right, down-left);
+                            * 8: MODE_HH, all eight neighbours (BASELINE config 5) */
 } rtdm_sgm_params;
 typedef struct rtdm_sgm rtdm_sgm;
 /* blockSize as given, minD 0, P1 600, P2 2400 (sgbm-sw.cpp:17-18), uniqueness 10, speckle 100/32,

@@ -99,6 +99,8 @@ def lib():
         L.orc_sgm_aggregate_paths.restype = None
         L.orc_sgm_select.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i16p, C.c_size_t]
         L.orc_sgm_select.restype = None
+        L.orc_median3x3_s16.argtypes = [i16p, C.c_size_t, i16p, C.c_size_t, C.c_int, C.c_int]
+        L.orc_median3x3_s16.restype = None
         L.orc_depth_stats.argtypes = [i16p, C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, C.c_size_t,
                                       C.POINTER(C.c_int), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_depth_stats.restype = C.c_int
@@ -241,6 +243,13 @@ def sgm_compute(left, right, **kw):
     return disp
 
 
+def median3x3(img):
+    img = np.ascontiguousarray(img, np.int16); H, W = img.shape
+    out = np.empty_like(img)
+    lib().orc_median3x3_s16(_p(img, C.c_int16), W, _p(out, C.c_int16), W, W, H)
+    return out
+
+
 def sgm_stages(left, right, **kw):
     """-> (pixel cost, block cost, aggregated S) as uint16 [H, W1, D] arrays, W1 = W - (minD + D) for minD >= 0."""
     left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
@@ -252,7 +261,9 @@ def sgm_stages(left, right, **kw):
     L = lib()
     L.orc_sgm_pixel_cost(_p(left, C.c_uint8), W, _p(right, C.c_uint8), W, W, H, minD, D, _p(pix, C.c_uint16))
     L.orc_sgm_block_cost(_p(pix, C.c_uint16), W1, H, D, p.blockSize, _p(Cc, C.c_uint16))
-    L.orc_sgm_aggregate_paths(_p(Cc, C.c_uint16), W1, H, D, p.P1, p.P2, 5 if p.paths == 5 else 8, _p(S, C.c_uint16))
+    P1 = p.P1 if p.P1 > 0 else 2
+    P2 = max(p.P2 if p.P2 > 0 else 5, P1 + 1)
+    L.orc_sgm_aggregate_paths(_p(Cc, C.c_uint16), W1, H, D, P1, P2, 5 if p.paths == 5 else 8, _p(S, C.c_uint16))
     return pix, Cc, S
 
 

@@ -49,7 +49,9 @@
  *     (sum + 16384) >> 15, saturate_cast not reachable for convex weights.  OpenCV builds the table by rounding float
  *     weights to short and fixing the sum to 32768 on the largest weight; the oracle's table construction follows that
  *     rule, but the tie rule for "largest weight" is from memory.
- *  H7 StereoSGBM (sgm_oracle.c): see that file's header; MODE_SGBM is restated from memory of stereosgbm.cpp 3.x.
+ *  H7 StereoSGBM (sgm_oracle.c): MODE_SGBM / MODE_HH restated from memory of stereosgbm.cpp 3.x, rules R1-R12 and three
+ *     knowing deviations in that file's header.  The rules most likely to differ between releases: R1's overwritten
+ *     border columns, R9's always-on check and its scaled initial value, R10's median (present since 2.4).
  */
 #ifndef RTDM_ORACLE_H_
 #define RTDM_ORACLE_H_
@@ -121,19 +123,19 @@ void orc_dilate(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep, in
 void orc_morph_open_close(const uint8_t* src, size_t sstep, uint8_t* dst, size_t dstep,
                           int W, int H);
 
-/* ---- SGM-8 (BASELINE config 5; defined in sgm_oracle.c) ------------------------------------------
+/* ---- cv::StereoSGBM (rows S / f4; BASELINE config 5; restated in sgm_oracle.c, rules R1-R12 there) -------------
  * Cost volumes are uint16 [H][W1][D] with W1 = the columns [minD+D, W+min(minD,0)). */
 typedef struct orc_sgm_params {
     int blockSize;          /* odd; sgbm-sw.cpp passes the constructor's blockSize               */
     int minDisparity;
     int numDisparities;     /* multiple of 16                                                    */
-    int P1, P2;             /* sgbm-sw.cpp:17-18 -> 600, 2400                                    */
-    int uniquenessRatio;
-    int speckleWindowSize;
+    int P1, P2;             /* sgbm-sw.cpp:17-18 -> 600, 2400; <= 0 -> 2 / 5, P2 >= P1 + 1 (R12)   */
+    int uniquenessRatio;    /* < 0 -> 10                                                           */
+    int speckleWindowSize;  /* > 0 enables filterSpeckles                                          */
     int speckleRange;       /* multiplied by 16 for filterSpeckles, as cv::StereoSGBM does        */
-    int disp12MaxDiff;      /* < 0 disables the left-right check                                  */
-    int paths;              /* 8 (BASELINE config 5; 0 means 8) or 5 = the directions of cv::StereoSGBM's default
-                             * MODE_SGBM, the mode sgbm-sw.cpp:15 gets: left, right, down, down-right, down-left */
+    int disp12MaxDiff;      /* <= 0 -> 1; the left-right check cannot be switched off (R9)        */
+    int paths;              /* 5 = MODE_SGBM, the mode sgbm-sw.cpp:15 gets (left, right, down, down-right, down-left);
+                             * 8 (or 0) = MODE_HH, all eight neighbours (BASELINE config 5)          */
 } orc_sgm_params;
 
 void orc_sgm_pixel_cost(const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep, int W, int H,
@@ -143,6 +145,7 @@ void orc_sgm_aggregate(const uint16_t* C, int W1, int H, int D, int P1, int P2, 
 void orc_sgm_aggregate_paths(const uint16_t* C, int W1, int H, int D, int P1, int P2, int paths, uint16_t* S);
 void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int uniquenessRatio, int disp12MaxDiff,
                     int16_t* disp, size_t dstep_elems);
+void orc_median3x3_s16(const int16_t* src, size_t sstep_elems, int16_t* dst, size_t dstep_elems, int W, int H);
 int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep,
                     int W, int H, int16_t* disp, size_t dstep_bytes);
 

@@ -1,30 +1,53 @@
 /*
- * sgm_oracle.c -- CPU oracle for BASELINE config 5: "SWSemiGlobalMatcher-equivalent (SGM 8-path cost
- * aggregation), d=128".
+ * sgm_oracle.c -- CPU restatement of what SWSemiGlobalMatcher::compute delegates to
+ * (/root/reference/stereo-matcher/sgbm-sw.cpp:32-37 -> cv::StereoSGBM::compute), rows S / f4 of SURVEY.md section 8.
  *
- * TEST INFRASTRUCTURE, PARITY UNPINNED -- see rtdm_oracle.h.  The reference's SWSemiGlobalMatcher
- * (/root/reference/stereo-matcher/sgbm-sw.cpp:12-37) is a wrapper over cv::StereoSGBM::create(0, nd,
- * blockSize) with P1 = 8*3*5*5 = 600 (:17), P2 = 32*3*5*5 = 2400 (:18), default mode (OpenCV MODE_SGBM,
- * 5 directions) and is never instantiated by main.cpp.  BASELINE config 5 asks for the 8-path variant,
- * so this file DEFINES the algorithm the HIP kernels are checked against ("SGM-8"), built from the
- * published pieces of cv::StereoSGBM, all in integer arithmetic:
+ * TEST INFRASTRUCTURE, PARITY UNPINNED -- see rtdm_oracle.h (hazard H7).  OpenCV is absent from the image and the
+ * reference holds no fixtures; what follows restates the PUBLISHED algorithm of OpenCV 3.x calib3d/stereosgbm.cpp
+ * (calcPixelCostBT, computeDisparitySGBM, StereoSGBMImpl::compute) from memory, in this project's own formulation
+ * (whole cost volumes, one pass per direction), anchored on the reference's call site:
+ *   sgbm-sw.cpp:15      StereoSGBM::create(0, nd, blockSize): preFilterCap 0, mode MODE_SGBM
+ *   sgbm-sw.cpp:16-24   P1 = 8*3*5*5 = 600, P2 = 32*3*5*5 = 2400, minDisparity, numDisparities, uniquenessRatio,
+ *                       speckleWindowSize, speckleRange, disp12MaxDiff from the constructor
  *
- *   pixel cost   Birchfield-Tomasi on the x-Sobel image clipped to +-15 (preFilterCap 0 -> ftzero 15)
- *                plus Birchfield-Tomasi on the raw intensities >> 2          (calcPixelCostBT)
- *   block cost   C(p,d) = sum of the pixel cost over blockSize x blockSize, coordinates clamped to
- *                the image (edge replication)
- *   path cost    L_r(p,d) = C(p,d) + min(L_r(q,d), L_r(q,d-1)+P1, L_r(q,d+1)+P1, min_k L_r(q,k)+P2)
- *                           - min_k L_r(q,k),  q = p - r;  L_r = C where q is outside the image;
- *                8 directions r; S = sum_r L_r
- *   selection    d* = first minimum of S; uniqueness: any |d-d*| > 1 with S[d]*(100-u) < S[d*]*100
- *                rejects; quadratic sub-pixel d*16 + ((S[d-1]-S[d+1])*16 + den)/(2*den),
- *                den = max(S[d-1]+S[d+1]-2S[d],1); left-right check on the integer winners
- *                (disp12MaxDiff); speckle filter with 16*speckleRange.
- * Domain: only columns x in [minD + D, W + min(minD,0)) can see every disparity, so -- like cv::StereoSGBM --
- * the cost volume, the block sums' edge replication and the paths live on that column range only
- * (W1 = its width); every other column is INVALID = (minD-1)*16.
- * Tolerance against this oracle: 0 (integer algorithm).  Against a real cv::StereoSGBM the result is
- * expected to differ (different direction set and border handling) -- that comparison is unpinned.
+ * paths = 5 is MODE_SGBM (what the reference creates): the directions left->right, right->left and the three that
+ * come down from the row above.  paths = 8 (BASELINE config 5, "8-path") is MODE_HH: all eight neighbours.  Rules
+ * restated, each with the place it has in the library:
+ *   R1 calcPixelCostBT   x-Sobel with the rows above / below REPLICATED at the frame edge, clipped to +-ftzero and
+ *                        offset by ftzero, ftzero = max(preFilterCap, 15) | 1 = 15; columns 0 and W-1 of BOTH the
+ *                        gradient row and the raw-intensity row are overwritten with ftzero before anything reads them;
+ *                        Birchfield-Tomasi dissimilarity with integer half-way points ((a + b) / 2), no half-way point
+ *                        beyond columns 0 / W-1; cost = BT(gradient) + (BT(raw) >> 2).
+ *   R2 domain            only columns x in [minX1, maxX1) = [max(minD+D,0), W+min(minD,0)) carry costs (width1 wide);
+ *                        everything else ends up INVALID = (minD-1)*16.
+ *   R3 block cost        sum of the pixel cost over SADWindowSize^2 with the first / last column of the DOMAIN and the
+ *                        first / last row of the frame replicated (the hsum/pixAdd/pixSub clamps); SADWindowSize =
+ *                        blockSize (the constructor argument).  The library adds P2 to every C and subtracts
+ *                        min_k + P2: the same numbers.
+ *   R4 path cost         L_r(p,d) = C(p,d) + min(L_r(q,d), L_r(q,d-1)+P1, L_r(q,d+1)+P1, min_k L_r(q,k)+P2) - min_k L_r(q,k),
+ *                        q = p - r; d-1 / d+1 outside [0,D) never win (MAX_COST sentinels); where q lies outside the
+ *                        domain the library's zeroed border buffers make L_r(p,d) = C(p,d).
+ *   R5 sum               S accumulates with saturate_cast<short>: since every L_r >= 0, S = min(sum_r L_r, 32767) however
+ *                        the additions are grouped.
+ *   R6 winner            scanning d upwards with a strict "<": the FIRST minimum; uniqueness: some d with |d - best| > 1
+ *                        and S[d]*(100-u) < minS*100 rejects; u = uniquenessRatio >= 0 ? it : 10.
+ *   R7 right view        columns are visited from RIGHT to LEFT; a winner votes for x2 = x - (best + minD) and replaces
+ *                        the vote there only if its minS is strictly smaller (ties: the larger x stays).
+ *   R8 sub-pixel         0 < d < D-1: d*16 + ((S[d-1]-S[d+1])*16 + den2) / (den2*2), den2 = max(S[d-1]+S[d+1]-2S[d], 1),
+ *                        C division; else d*16; + minD*16.
+ *   R9 left-right check  ALWAYS on, with disp12MaxDiff > 0 ? it : 1: a pixel is invalidated iff both x - (d>>4) and
+ *                        x - ((d+15)>>4) lie in the row, hold a vote ">= minD" and differ from it by more than the limit.
+ *                        The vote array is initialised with the SCALED invalid value (minD-1)*16, which is ">= minD"
+ *                        for minD >= 2 (a quirk that is restated, not repaired).
+ *   R10 median           medianBlur(disp, disp, 3): 3x3 median of the int16 map, coordinates clamped (BORDER_REPLICATE).
+ *   R11 speckle          if speckleWindowSize > 0: filterSpeckles(disp, (minD-1)*16, window, 16 * speckleRange).
+ *   R12 parameters       P1 = P1 > 0 ? P1 : 2, P2 = max(P2 > 0 ? P2 : 5, P1+1).
+ * Knowing deviations: (a) the library's CostType is short and wraps above 32767; configurations where
+ * 93 * blockSize^2 + P2 can exceed that are refused here (blockSize <= 17 at P2 = 2400) instead of restating the
+ * wrap-around; (b) even block sizes are refused (the library takes them and uses an odd window of blockSize/2*2+1);
+ * (c) for minD != 0 the library precomputes the right image's Birchfield-Tomasi bounds over [minX2, maxX2) only,
+ * which does not cover every column the cost loop reads -- the bounds are computed for every column here.
+ * Tolerance of the HIP kernels against this file: 0 (integer algorithm).
  */
 #include "rtdm_oracle.h"
 
@@ -76,17 +99,25 @@ void orc_sgm_pixel_cost(const uint8_t* L, size_t lstep, const uint8_t* R, size_t
     const int x0 = imax(minD + D, 0), x1 = W + imin(minD, 0), W1 = x1 - x0;
     uint8_t* gl = (uint8_t*)malloc((size_t)W * H);
     uint8_t* gr = (uint8_t*)malloc((size_t)W * H);
+    uint8_t* il = (uint8_t*)malloc((size_t)W * H);      /* R1: raw rows with columns 0 and W-1 overwritten by ftzero */
+    uint8_t* ir = (uint8_t*)malloc((size_t)W * H);
     sgm_gradient(L, lstep, W, H, gl);
     sgm_gradient(R, rstep, W, H, gr);
+    for (int y = 0; y < H; ++y) {
+        memcpy(il + (size_t)y * W, L + (size_t)y * lstep, (size_t)W);
+        memcpy(ir + (size_t)y * W, R + (size_t)y * rstep, (size_t)W);
+        il[(size_t)y * W] = il[(size_t)y * W + W - 1] = SGM_FTZERO;
+        ir[(size_t)y * W] = ir[(size_t)y * W + W - 1] = SGM_FTZERO;
+    }
     for (int y = 0; y < H; ++y)
         for (int x = x0; x < x1; ++x)
             for (int d = 0; d < D; ++d) {
                 const int xr = x - (d + minD);      /* always inside the image on this domain */
                 const int c = bt(gl + (size_t)y * W, x, gr + (size_t)y * W, xr, W) +
-                              (bt(L + (size_t)y * lstep, x, R + (size_t)y * rstep, xr, W) >> 2);
+                              (bt(il + (size_t)y * W, x, ir + (size_t)y * W, xr, W) >> 2);
                 cost[((size_t)y * W1 + (x - x0)) * D + d] = (uint16_t)c;
             }
-    free(gr); free(gl);
+    free(ir); free(il); free(gr); free(gl);
 }
 
 void orc_sgm_block_cost(const uint16_t* pix, int W, int H, int D, int blockSize, uint16_t* C)
@@ -137,7 +168,7 @@ static void sgm_path(const uint16_t* C, int W, int H, int D, int dx, int dy, int
                     }
                     cur[d + 1] = l;
                     mincur = imin(mincur, l);
-                    s[d] = (uint16_t)(s[d] + l);
+                    s[d] = (uint16_t)imin((int)s[d] + l, 32767);      /* R5: saturate_cast<short>, all terms >= 0 */
                 }
                 int* t = prev; prev = cur; cur = t;
                 minprev = mincur; first = 0;
@@ -152,7 +183,7 @@ void orc_sgm_aggregate_paths(const uint16_t* C, int W, int H, int D, int P1, int
     static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1}};
     memset(S, 0, sizeof(uint16_t) * (size_t)W * H * D);
     for (int k = 0; k < 8; ++k) {
-        if (paths == 5 && dirs[k][1] < 0) continue;        /* MODE_SGBM: no path that runs upwards */
+        if (paths == 5 && dirs[k][1] < 0) continue;        /* MODE_SGBM: no path that runs upwards (R4) */
         sgm_path(C, W, H, D, dirs[k][0], dirs[k][1], P1, P2, S);
     }
 }
@@ -165,21 +196,24 @@ void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int unique
 {
     const int INVALID = (minD - 1) * 16;
     const int minX1 = imax(minD + D, 0), maxX1 = W + imin(minD, 0), W1 = maxX1 - minX1;
+    const int uniq = uniquenessRatio >= 0 ? uniquenessRatio : 10;          /* R6 */
+    const int maxDiff = disp12MaxDiff > 0 ? disp12MaxDiff : 1;            /* R9: never off */
     int* d2 = (int*)malloc(sizeof(int) * 2 * (size_t)W);
     int* c2 = d2 + W;
     for (int y = 0; y < H; ++y) {
         int16_t* out = disp + (size_t)y * dstep;
-        for (int x = 0; x < W; ++x) { out[x] = (int16_t)INVALID; d2[x] = minD - 1; c2[x] = INT_MAX; }
-        for (int x = minX1; x < maxX1; ++x) {
+        for (int x = 0; x < W; ++x) { out[x] = (int16_t)INVALID; d2[x] = INVALID; c2[x] = SHRT_MAX; }   /* R9: the scaled value */
+        for (int x = maxX1 - 1; x >= minX1; --x) {                                                      /* R7: right to left */
             const uint16_t* s = S + ((size_t)y * W1 + (x - minX1)) * D;
-            int mins = INT_MAX, bd = -1;
+            int mins = SHRT_MAX, bd = -1;
             for (int d = 0; d < D; ++d) if (s[d] < mins) { mins = s[d]; bd = d; }
+            if (bd < 0) continue;            /* every S saturated: the library's bestDisp stays -1; not reachable below the cap */
             int d;
             for (d = 0; d < D; ++d)
-                if (iabs(d - bd) > 1 && (int)s[d] * (100 - uniquenessRatio) < mins * 100) break;
+                if ((int)s[d] * (100 - uniq) < mins * 100 && iabs(bd - d) > 1) break;
             if (d < D) continue;
-            {   /* vote for the matching right-image column with the integer winner */
-                const int x2 = x - (bd + minD);
+            {
+                const int x2 = x - bd - minD;                     /* inside the row on this domain */
                 if (x2 >= 0 && x2 < W && c2[x2] > mins) { c2[x2] = mins; d2[x2] = bd + minD; }
             }
             int d16;
@@ -189,18 +223,36 @@ void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int unique
             } else d16 = bd * 16;
             out[x] = (int16_t)(d16 + minD * 16);
         }
-        if (disp12MaxDiff >= 0)
-            for (int x = minX1; x < maxX1; ++x) {
-                const int d1 = out[x];
-                if (d1 == INVALID) continue;
-                const int da = d1 >> 4, db = (d1 + 15) >> 4;
-                const int xa = x - da, xb = x - db;
-                if (0 <= xa && xa < W && d2[xa] >= minD && iabs(d2[xa] - da) > disp12MaxDiff &&
-                    0 <= xb && xb < W && d2[xb] >= minD && iabs(d2[xb] - db) > disp12MaxDiff)
-                    out[x] = (int16_t)INVALID;
-            }
+        for (int x = minX1; x < maxX1; ++x) {
+            const int d1 = out[x];
+            if (d1 == INVALID) continue;
+            const int da = d1 >> 4, db = (d1 + 15) >> 4;
+            const int xa = x - da, xb = x - db;
+            if (0 <= xa && xa < W && d2[xa] >= minD && iabs(d2[xa] - da) > maxDiff &&
+                0 <= xb && xb < W && d2[xb] >= minD && iabs(d2[xb] - db) > maxDiff)
+                out[x] = (int16_t)INVALID;
+        }
     }
     free(d2);
+}
+
+/* R10: 3x3 median of an int16 image, coordinates clamped to the frame (what medianBlur's BORDER_REPLICATE does). */
+void orc_median3x3_s16(const int16_t* src, size_t sstep, int16_t* dst, size_t dstep, int W, int H)
+{
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int v[9], n = 0;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx)
+                    v[n++] = src[(size_t)iclamp(y + dy, 0, H - 1) * sstep + iclamp(x + dx, 0, W - 1)];
+            for (int i = 1; i < 9; ++i) {                    /* insertion sort: the definition, not a network */
+                const int t = v[i];
+                int j = i - 1;
+                while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; --j; }
+                v[j + 1] = t;
+            }
+            dst[(size_t)y * dstep + x] = (int16_t)v[4];
+        }
 }
 
 int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep,
@@ -209,23 +261,30 @@ int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, con
     if (!p || !L || !R || !disp || W <= 0 || H <= 0) return ORC_ERR_BAD_SIZE;
     const int D = p->numDisparities, minD = p->minDisparity;
     if (D <= 0 || D % 16 != 0 || p->blockSize < 1 || (p->blockSize & 1) == 0) return ORC_ERR_BAD_PARAM;
-    if (p->P1 <= 0 || p->P2 <= p->P1 || p->uniquenessRatio < 0 || p->uniquenessRatio > 100) return ORC_ERR_BAD_PARAM;
+    if (p->uniquenessRatio > 100) return ORC_ERR_BAD_PARAM;
     if (p->paths != 0 && p->paths != 5 && p->paths != 8) return ORC_ERR_BAD_PARAM;
+    const int P1 = p->P1 > 0 ? p->P1 : 2;                                 /* R12 */
+    const int P2 = imax(p->P2 > 0 ? p->P2 : 5, P1 + 1);
+    if (93L * p->blockSize * p->blockSize + P2 > 32767) return ORC_ERR_BAD_PARAM;     /* deviation (a): 16-bit costs would wrap */
+    const size_t dstep = dstep_bytes / 2;
+    const int INVALID = (minD - 1) * 16;
     const int W1 = (W + imin(minD, 0)) - imax(minD + D, 0);
-    if (W1 <= 0) {
-        for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) disp[(size_t)y * (dstep_bytes / 2) + x] = (int16_t)((minD - 1) * 16);
+    if (W1 <= 0) {      /* the library returns before the median and the speckle filter; they would change nothing */
+        for (int y = 0; y < H; ++y) for (int x = 0; x < W; ++x) disp[(size_t)y * dstep + x] = (int16_t)INVALID;
         return ORC_OK;
     }
     const size_t vol = (size_t)W1 * H * D;
     uint16_t* pix = (uint16_t*)malloc(vol * 2);
     uint16_t* C = (uint16_t*)malloc(vol * 2);
     uint16_t* S = (uint16_t*)malloc(vol * 2);
+    int16_t* raw = (int16_t*)malloc(sizeof(int16_t) * (size_t)W * H);
     orc_sgm_pixel_cost(L, lstep, R, rstep, W, H, minD, D, pix);
     orc_sgm_block_cost(pix, W1, H, D, p->blockSize, C);
-    orc_sgm_aggregate_paths(C, W1, H, D, p->P1, p->P2, p->paths == 5 ? 5 : 8, S);
-    orc_sgm_select(S, W, H, D, minD, p->uniquenessRatio, p->disp12MaxDiff, disp, dstep_bytes / 2);
-    if (p->speckleWindowSize > 0 && p->speckleRange >= 0)
-        orc_filter_speckles(disp, dstep_bytes / 2, W, H, (minD - 1) * 16, p->speckleWindowSize, 16 * p->speckleRange);
-    free(S); free(C); free(pix);
+    orc_sgm_aggregate_paths(C, W1, H, D, P1, P2, p->paths == 5 ? 5 : 8, S);
+    orc_sgm_select(S, W, H, D, minD, p->uniquenessRatio, p->disp12MaxDiff, raw, (size_t)W);
+    orc_median3x3_s16(raw, (size_t)W, disp, dstep, W, H);                 /* R10 */
+    if (p->speckleWindowSize > 0)                                         /* R11 */
+        orc_filter_speckles(disp, dstep, W, H, INVALID, p->speckleWindowSize, 16 * p->speckleRange);
+    free(raw); free(S); free(C); free(pix);
     return ORC_OK;
 }

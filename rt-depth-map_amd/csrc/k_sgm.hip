@@ -1,20 +1,18 @@
-// k_sgm.hip -- BASELINE config 5: semi-global matching with 8-path cost aggregation ("SGM-8"), the
-// device counterpart of the reference's SWSemiGlobalMatcher (/root/reference/stereo-matcher/
-// sgbm-sw.cpp:12-37 -> cv::StereoSGBM, P1 = 600, P2 = 2400).  The algorithm is the one defined by
-// oracle/sgm_oracle.c (integer arithmetic, tolerance 0 against that oracle; parity against a real
-// cv::StereoSGBM is unpinned).  Cost volumes live on the column domain [x0, x1) = [minD+D, W+min(minD,0))
-// and are laid out [frame][y][x - x0][d] with d fastest, so a wavefront's lanes = consecutive
-// disparities = one coalesced line per pixel.
+// k_sgm.hip -- the device counterpart of the reference's SWSemiGlobalMatcher (/root/reference/stereo-matcher/
+// sgbm-sw.cpp:12-37 -> cv::StereoSGBM, P1 = 600, P2 = 2400): paths = 5 is the library's MODE_SGBM (what sgbm-sw.cpp:15
+// creates), paths = 8 its MODE_HH (BASELINE config 5, "8-path").  The algorithm is the restatement in
+// oracle/sgm_oracle.c (rules R1-R12 there; integer arithmetic, tolerance 0 against that oracle; parity against a real
+// cv::StereoSGBM is unpinned).  Cost volumes live on the column domain [x0, x1) = [minD+D, W+min(minD,0)) and are laid
+// out [frame][y][x - x0][d] with d fastest, so a wavefront's lanes = consecutive disparities = one coalesced line per pixel.
 //
 //   k_sgm_bounds x-Sobel (vertical edge replication) clipped to +-15, + 15, and the BT bounds of it and of the
-//                intensity, per pixel                                                  (HBM bound)
+//                intensity (border columns overwritten with 15, R1), per pixel          (HBM bound)
 //   k_sgm_pix    Birchfield-Tomasi pixel cost, gradient + (intensity >> 2) -> u8      (thread = 4 d)
 //   k_sgm_box    blockSize x blockSize sum with clamped coordinates -> C (u16)
-//   k_sgm_path   one workgroup per path line, one thread per disparity: L_r recurrence with the
-//                neighbours and the line minimum exchanged through double-buffered LDS (one barrier
-//                per pixel), S += L_r; launched once per direction (8x)
-//   k_sgm_select one workgroup per row: winner-take-all, uniqueness, quadratic sub-pixel, left-right
-//                check on the integer winners (LDS votes), optional speckle-filter init
+//   k_sgm_path_w one WAVE per path line: L_r recurrence, S = min(S + L_r, 32767) (R5); launched once per direction
+//   k_sgm_select one workgroup per row: winner-take-all, uniqueness, quadratic sub-pixel, left-right check on the
+//                integer winners (LDS votes, right-most voter wins ties: R7)
+//   k_sgm_median 3x3 median with clamped coordinates (R10) + the speckle filter's per-row init
 #include "rtdm_kernels.h"
 #include "rtdm_device.h"
 
@@ -55,7 +53,9 @@ __global__ __launch_bounds__(256) void k_sgm_bounds(Plane8 L, Plane8 R, uint2* b
     const bool hm = x > 0, hp = x < W - 1;
     const uint32_t gb = bt_pack(sgm_grad(r0, r1, r2, x, W), hm ? sgm_grad(r0, r1, r2, x - 1, W) : 0,
                                 hp ? sgm_grad(r0, r1, r2, x + 1, W) : 0, hm, hp);
-    const uint32_t rb = bt_pack(r1[x], hm ? r1[x - 1] : 0, hp ? r1[x + 1] : 0, hm, hp);
+    // R1: the library overwrites columns 0 and W-1 of the raw-intensity row with ftzero as well, before the bounds are taken
+    const auto raw = [&](int i) -> int { return (i <= 0 || i >= W - 1) ? FTZ : (int)r1[i]; };
+    const uint32_t rb = bt_pack(raw(x), hm ? raw(x - 1) : 0, hp ? raw(x + 1) : 0, hm, hp);
     (right ? br : bl)[((size_t)f * H + y) * W + x] = make_uint2(gb, rb);
 }
 
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_sgm_path(const uint16_t* C, uint16_t* S
             l = c + best - mprev;
         }
         if (live) {
-            if (first_dir) S[off] = (uint16_t)l; else S[off] = (uint16_t)(S[off] + l);
+            if (first_dir) S[off] = (uint16_t)l; else S[off] = (uint16_t)min((int)S[off] + l, 32767);   // R5
         }
         int* cb = lbuf[step & 1];
         cb[d + 1] = live ? l : BIG;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void k_sgm_path_w(const uint16_t* C, uint16_t*
             if (live) {
                 int o[NPL];
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) o[j] = first_dir ? l[j] : (int)sv.v[j] + l[j];
+                for (int j = 0; j < NPL; ++j) o[j] = first_dir ? l[j] : min((int)sv.v[j] + l[j], 32767);   // R5: saturating sum
                 st_pack<NPL>(sp + (long)step * stride, o);
             }
             int m = l[0];
@@ -364,7 +364,9 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
         if (lane == 0) {
             const int x = g.x0 + xi;
             const int x2 = x - (bd + minD);
-            if (x2 >= 0 && x2 < W) atomicMin(&key[x2], ((unsigned long long)(unsigned)mins << 32) | (unsigned)x);
+            // R7: the library walks the row from right to left and replaces a vote only by a strictly smaller cost, so among
+            // equal costs the right-most voter stays: the key's low word grows to the left
+            if (x2 >= 0 && x2 < W) atomicMin(&key[x2], ((unsigned long long)(unsigned)mins << 32) | (unsigned)(0xffff - x));
             bdv[x] = (int16_t)(bd + minD);
             int d16 = bd * 16;
             if (bd > 0 && bd < D - 1) {
@@ -380,12 +382,15 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
     int16_t* fin = (int16_t*)(row + W);                      // W : final row (for the speckle init)
     for (int x = threadIdx.x; x < W; x += 256) {
         int d1 = row[x];
-        if (disp12MaxDiff >= 0 && d1 != INV) {
+        if (d1 != INV) {                                      // R9: always on (the host passes disp12MaxDiff > 0 ? it : 1)
             const int da = d1 >> 4, db = (d1 + 15) >> 4;
             const int xa = x - da, xb = x - db;
+            // a column nobody voted for holds the library's initial value, the SCALED invalid disparity, which passes its
+            // ">= minD" test for minD >= 2 (restated, not repaired)
+            const auto vote = [&](int xv) -> int { return key[xv] != ~0ull ? (int)bdv[0xffff - (unsigned)(key[xv] & 0xffffu)] : INV; };
             bool ba = false, bb = false;
-            if (xa >= 0 && xa < W && key[xa] != ~0ull) ba = abs((int)bdv[(unsigned)(key[xa] & 0xffffffffu)] - da) > disp12MaxDiff;
-            if (xb >= 0 && xb < W && key[xb] != ~0ull) bb = abs((int)bdv[(unsigned)(key[xb] & 0xffffffffu)] - db) > disp12MaxDiff;
+            if (xa >= 0 && xa < W) { const int v = vote(xa); ba = v >= minD && abs(v - da) > disp12MaxDiff; }
+            if (xb >= 0 && xb < W) { const int v = vote(xb); bb = v >= minD && abs(v - db) > disp12MaxDiff; }
             if (ba && bb) d1 = INV;
         }
         out[x] = (int16_t)d1;
@@ -394,6 +399,39 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
     if (SPK) {
         __syncthreads();
         spk_row_init(fin, (int*)key, wsum, W, (f * g.H + y) * W, label, size, runs, rowcnt + (f * g.H + y), headmap, INV, spkDiff);
+    }
+}
+
+// R10: medianBlur(disp, disp, 3) -- 3x3 median of the int16 map with clamped coordinates -- followed by the speckle
+// filter's per-row init on the filtered row.  One workgroup per row; the three source rows stream through L2.
+__device__ __forceinline__ void mnmx(int& a, int& b) { const int t = min(a, b); b = max(a, b); a = t; }
+template <bool SPK>
+__global__ __launch_bounds__(256) void k_sgm_median(const int16_t* src, Plane16W disp, int W, int H, int INV, int32_t* label,
+                                                    int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap, int spkDiff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* sc = (int*)smem;                                   // W : scan scratch of the speckle init
+    int16_t* fin = (int16_t*)(sc + W);                      // W : the filtered row
+    __shared__ int wsum[4];
+    const int y = blockIdx.y, f = blockIdx.z;
+    const int16_t* base = src + (size_t)f * H * W;
+    const int16_t* r0 = base + (size_t)max(y - 1, 0) * W;
+    const int16_t* r1 = base + (size_t)y * W;
+    const int16_t* r2 = base + (size_t)min(y + 1, H - 1) * W;
+    int16_t* out = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        const int xm = max(x - 1, 0), xp = min(x + 1, W - 1);
+        int p0 = r0[xm], p1 = r0[x], p2 = r0[xp], p3 = r1[xm], p4 = r1[x], p5 = r1[xp], p6 = r2[xm], p7 = r2[x], p8 = r2[xp];
+        // median-of-nine exchange network (19 exchanges)
+        mnmx(p1, p2); mnmx(p4, p5); mnmx(p7, p8); mnmx(p0, p1); mnmx(p3, p4); mnmx(p6, p7); mnmx(p1, p2); mnmx(p4, p5);
+        mnmx(p7, p8); mnmx(p0, p3); mnmx(p5, p8); mnmx(p4, p7); mnmx(p3, p6); mnmx(p1, p4); mnmx(p2, p5); mnmx(p4, p7);
+        mnmx(p4, p2); mnmx(p6, p4); mnmx(p4, p2);
+        out[x] = (int16_t)p4;
+        if (SPK) fin[x] = (int16_t)p4;
+    }
+    if (SPK) {
+        __syncthreads();
+        spk_row_init(fin, sc, wsum, W, (f * H + y) * W, label, size, runs, rowcnt + (f * H + y), headmap, INV, spkDiff);
     }
 }
 
@@ -417,11 +455,11 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     {
         const int rps = 48, strips = (g.H + rps - 1) / rps;
         const dim3 bgrid(nxd, strips, n);
-        switch (blockSize / 2) {
-            case 0: hipLaunchKernelGGL(k_sgm_box<0>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
-            case 1: hipLaunchKernelGGL(k_sgm_box<1>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
-            case 2: hipLaunchKernelGGL(k_sgm_box<2>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
-            default: hipLaunchKernelGGL(k_sgm_box<3>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+        switch (blockSize / 2) {                      // blockSize <= 17 (rtdm_sgm_create: 93 * blockSize^2 + P2 <= 32767)
+#define RTDM_BOX(RR) case RR: hipLaunchKernelGGL(k_sgm_box<RR>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+            RTDM_BOX(0) RTDM_BOX(1) RTDM_BOX(2) RTDM_BOX(3) RTDM_BOX(4) RTDM_BOX(5) RTDM_BOX(6) RTDM_BOX(7)
+            default: hipLaunchKernelGGL(k_sgm_box<8>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+#undef RTDM_BOX
         }
     }
     static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1}};
@@ -448,14 +486,22 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
             hipLaunchKernelGGL(k_sgm_path, dim3(lines, n), dim3(threads), 0, stream, b.C, b.S, g, dx, dy, P1, P2, k == 0 ? 1 : 0);
         }
     }
-    const bool speckle = speckleWindowSize > 0 && speckleRange >= 0;
+    const bool speckle = speckleWindowSize > 0;                           // R11
     const size_t lds = (size_t)g.W * (8 + 2 + 2 + 2);
+    // select -> a temporary plane (the bounds buffer of the left image is free again), median -> the caller's plane
+    int16_t* tmp = (int16_t*)b.gl;
+    const Plane16W tplane{tmp, (size_t)g.W, (size_t)g.W * g.H};
+    launch_select<false>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, tplane, g, uniq, disp12MaxDiff, b, 0);
+    const size_t mlds = (size_t)g.W * 6;
+    const int INV = (g.minD - 1) * 16;
     if (speckle) {
-        launch_select<true>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, disp, g, uniq, disp12MaxDiff, b, 16 * speckleRange);
-        launch_speckle(disp, b.label, b.size, b.runs, b.rowcnt, b.headmap, g.W, g.W, g.H, n, (g.minD - 1) * 16, speckleWindowSize,
+        hipLaunchKernelGGL((k_sgm_median<true>), dim3(1, g.H, n), blk, mlds, stream, tmp, disp, g.W, g.H, INV, b.label, b.size, b.runs,
+                           b.rowcnt, b.headmap, 16 * speckleRange);
+        launch_speckle(disp, b.label, b.size, b.runs, b.rowcnt, b.headmap, g.W, g.W, g.H, n, INV, speckleWindowSize,
                        16 * speckleRange, true, 1, 0, g.H, stream);
     } else {
-        launch_select<false>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, disp, g, uniq, disp12MaxDiff, b, 0);
+        hipLaunchKernelGGL((k_sgm_median<false>), dim3(1, g.H, n), blk, mlds, stream, tmp, disp, g.W, g.H, INV, b.label, b.size, b.runs,
+                           b.rowcnt, b.headmap, 0);
     }
 }
 

@@ -819,14 +819,20 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
 {
     if (!params || !out) return RTDM_ERR_NULL;
     *out = nullptr;
-    const rtdm_sgm_params& p = *params;
+    rtdm_sgm_params p = *params;
     if (p.numDisparities <= 0 || p.numDisparities % 16 != 0 || p.blockSize < 1 || (p.blockSize & 1) == 0) return RTDM_ERR_BAD_PARAM;
-    if (p.P1 <= 0 || p.P2 <= p.P1 || p.uniquenessRatio < 0 || p.uniquenessRatio > 100) return RTDM_ERR_BAD_PARAM;
+    if (p.uniquenessRatio > 100) return RTDM_ERR_BAD_PARAM;
     if (p.paths != 5 && p.paths != 8) return RTDM_ERR_BAD_PARAM;
+    // what cv::StereoSGBM does with out-of-range knobs (oracle/sgm_oracle.c R6, R9, R12): it coerces them
+    if (p.P1 <= 0) p.P1 = 2;
+    p.P2 = std::max(p.P2 > 0 ? p.P2 : 5, p.P1 + 1);
+    if (p.uniquenessRatio < 0) p.uniquenessRatio = 10;
+    if (p.disp12MaxDiff <= 0) p.disp12MaxDiff = 1;         // the library's left-right check cannot be switched off
     if (max_width <= 0 || max_height <= 0 || max_batch <= 0) return RTDM_ERR_BAD_SIZE;
     if (p.numDisparities > 256 || max_width > 4096) return RTDM_ERR_UNSUPPORTED;
-    // the aggregated volume is uint16: 8 paths x (block cost + P2) must fit (pixel cost <= 30 + 63)
-    if (8L * ((long)p.blockSize * p.blockSize * 93 + p.P2) > 65535) return RTDM_ERR_UNSUPPORTED;
+    // 16-bit costs: a path cost is at most block cost + P2 (pixel cost <= 30 + 63); above 32767 the library's short
+    // arithmetic wraps, which is not restated (blockSize <= 17 at P2 = 2400)
+    if (93L * p.blockSize * p.blockSize + p.P2 > 32767) return RTDM_ERR_UNSUPPORTED;
     int rc = use_device(device);
     if (rc) return rc;
     rtdm_sgm* sg = new (std::nothrow) rtdm_sgm();

@@ -1,7 +1,9 @@
 /*
  * sgbm-hip.h -- install as include/stereo-matcher/sgbm-hip.h.  HIPSemiGlobalMatcher derives from the reference's
  * BlockMatcher with SWSemiGlobalMatcher's constructor (include/stereo-matcher/sgbm-sw.h:27-28) plus the frame size.
- * Like SWSemiGlobalMatcher it is not selected by main.cpp unless the maintainer does so.
+ * Like SWSemiGlobalMatcher it is not selected by main.cpp unless the maintainer does so.  The device module runs
+ * cv::StereoSGBM's MODE_SGBM as restated in oracle/sgm_oracle.c (bit-exact against that restatement; against the
+ * library itself parity is unpinned); blockSize must be odd and <= 17 at the reference's P2 = 2400.
  */
 #ifndef INCLUDE_BM_SGBM_HIP_H_
 #define INCLUDE_BM_SGBM_HIP_H_

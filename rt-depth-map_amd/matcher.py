@@ -119,7 +119,7 @@ class HIPSemiGlobalMatcher:
 
     def __init__(self, blockSize=5, minDisparity=0, numOfDisparities=128, uniquenessRatio=10, speckleWindowSize=100,
                  speckleRange=32, disp12MaxDiff=1, P1=600, P2=2400, width=1280, height=720, max_batch=1, device=0, paths=8):
-        # paths: 8 (BASELINE config 5) or 5 = the directions of cv::StereoSGBM's default mode (what sgbm-sw.cpp:15 creates)
+        # paths: 5 = cv::StereoSGBM's default MODE_SGBM (what sgbm-sw.cpp:15 creates), 8 = MODE_HH (BASELINE config 5)
         self._h = C.c_void_p()
         self.params = B.SGMParams(blockSize, minDisparity, numOfDisparities, P1, P2, uniquenessRatio, speckleWindowSize,
                                   speckleRange, disp12MaxDiff, paths)

@@ -197,7 +197,8 @@ def morph_open_close(img):
     return morph(morph(morph(morph(img, False), True), True), False)
 
 
-# ---- SGM-8 (BASELINE config 5), second implementation, straight from the definition -----------------
+# ---- cv::StereoSGBM restated a second time (MODE_SGBM = 5 paths, MODE_HH = 8), straight from the rules R1-R12 listed
+# ---- in oracle/sgm_oracle.c; nothing is shared with that file ------------------------------------------------------
 def _sgm_grad(img):
     img = img.astype(np.int64)
     H, W = img.shape
@@ -221,7 +222,9 @@ def sgm_volumes(L, R, D, minD=0, blockSize=5, P1=600, P2=2400, paths=8):
     x0, x1 = max(minD + D, 0), W + min(minD, 0)
     W1 = x1 - x0
     pix = np.zeros((H, W1, D), np.int64)
-    for a, b, sh in ((_sgm_grad(L), _sgm_grad(R), 0), (L, R, 2)):
+    Lb, Rb = L.astype(np.int64).copy(), R.astype(np.int64).copy()
+    Lb[:, 0] = Lb[:, -1] = 15; Rb[:, 0] = Rb[:, -1] = 15        # R1: the raw rows' border columns are overwritten too
+    for a, b, sh in ((_sgm_grad(L), _sgm_grad(R), 0), (Lb, Rb, 2)):
         u, u0, u1 = _bt_bounds(a)
         v, v0, v1 = _bt_bounds(b)
         xs = np.arange(x0, x1)
@@ -256,7 +259,16 @@ def sgm_volumes(L, R, D, minD=0, blockSize=5, P1=600, P2=2400, paths=8):
                 else:
                     Lr[y, x] = C[y, x]
         S += Lr
+    S = np.minimum(S, 32767)                           # R5: saturating 16-bit sum of non-negative terms
     return pix, C, S
+
+
+def median3x3(img):
+    """R10: 3x3 median with clamped coordinates."""
+    p = np.pad(img.astype(np.int64), 1, mode="edge")
+    H, W = img.shape
+    st = np.stack([p[dy:dy + H, dx:dx + W] for dy in range(3) for dx in range(3)])
+    return np.sort(st, axis=0)[4]
 
 
 def sgm(L, R, numDisparities=32, minDisparity=0, blockSize=5, P1=600, P2=2400, uniquenessRatio=10,
@@ -268,17 +280,23 @@ def sgm(L, R, numDisparities=32, minDisparity=0, blockSize=5, P1=600, P2=2400, u
     x0, x1 = max(minD + D, 0), W + min(minD, 0)
     if x1 - x0 <= 0:
         return out.astype(np.int16)
+    P1 = P1 if P1 > 0 else 2                                           # R12
+    P2 = max(P2 if P2 > 0 else 5, P1 + 1)
+    uniq = uniquenessRatio if uniquenessRatio >= 0 else 10             # R6
+    maxdiff = disp12MaxDiff if disp12MaxDiff > 0 else 1                # R9: the check is never off
     _, _, S = sgm_volumes(L, R, D, minD, blockSize, P1, P2, paths)
     for y in range(H):
-        d2 = [minD - 1] * W; c2 = [None] * W
-        for x in range(x0, x1):
+        d2 = [INV] * W; c2 = [32767] * W                               # R9: initialised with the scaled invalid value
+        for x in range(x1 - 1, x0 - 1, -1):                            # R7: right to left
             s = S[y, x - x0]
             bd = int(np.argmin(s)); mins = int(s[bd])
-            far = np.abs(np.arange(D) - bd) > 1
-            if np.any(far & (s * (100 - uniquenessRatio) < mins * 100)):
+            if mins >= 32767:
                 continue
-            x2 = x - (bd + minD)
-            if 0 <= x2 < W and (c2[x2] is None or c2[x2] > mins):
+            far = np.abs(np.arange(D) - bd) > 1
+            if np.any(far & (s * (100 - uniq) < mins * 100)):
+                continue
+            x2 = x - bd - minD
+            if 0 <= x2 < W and c2[x2] > mins:
                 c2[x2] = mins; d2[x2] = bd + minD
             if 0 < bd < D - 1:
                 den = max(int(s[bd - 1]) + int(s[bd + 1]) - 2 * mins, 1)
@@ -288,18 +306,18 @@ def sgm(L, R, numDisparities=32, minDisparity=0, blockSize=5, P1=600, P2=2400, u
             else:
                 d16 = bd * 16
             out[y, x] = d16 + minD * 16
-        if disp12MaxDiff >= 0:
-            row = out[y].copy()
-            for x in range(x0, x1):
-                d1 = int(row[x])
-                if d1 == INV:
-                    continue
-                da, db = d1 >> 4, (d1 + 15) >> 4
-                xa, xb = x - da, x - db
-                if (0 <= xa < W and d2[xa] >= minD and abs(d2[xa] - da) > disp12MaxDiff and
-                        0 <= xb < W and d2[xb] >= minD and abs(d2[xb] - db) > disp12MaxDiff):
-                    out[y, x] = INV
-    if speckleWindowSize > 0 and speckleRange >= 0:
+        row = out[y].copy()
+        for x in range(x0, x1):
+            d1 = int(row[x])
+            if d1 == INV:
+                continue
+            da, db = d1 >> 4, (d1 + 15) >> 4
+            xa, xb = x - da, x - db
+            if (0 <= xa < W and d2[xa] >= minD and abs(d2[xa] - da) > maxdiff and
+                    0 <= xb < W and d2[xb] >= minD and abs(d2[xb] - db) > maxdiff):
+                out[y, x] = INV
+    out = median3x3(out)
+    if speckleWindowSize > 0:                                          # R11
         out = speckle(out.astype(np.int16), INV, speckleWindowSize, 16 * speckleRange).astype(np.int64)
     return out.astype(np.int16)
 

@@ -66,17 +66,19 @@ def test_random_block_matching_configuration(pkg, oracle, synth, seed):
             seed, W, H, kw, roi1, roi2, variant, len(bad), tuple(bad[0]), got[tuple(bad[0])], want[tuple(bad[0])]))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(16))
 def test_random_sgm_configuration(pkg, oracle, synth, seed):
+    # cv::StereoSGBM as restated in oracle/sgm_oracle.c: both modes, any odd blockSize the 16-bit costs allow (<= 17 at the
+    # reference's P2), the library's coercion of out-of-range P1 / P2 / uniquenessRatio / disp12MaxDiff
     rng = np.random.default_rng(2000 + seed)
     D = int(rng.choice([16, 32, 64, 128, 192]))
-    bs = int(rng.choice([1, 3, 5, 7]))
+    bs = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 17]))
     minD = int(rng.choice([0, 0, 2, -3]))
     W, H = int(rng.integers(D + 30, D + 150)), int(rng.integers(12, 60))
-    kw = dict(blockSize=bs, minDisparity=minD, uniquenessRatio=int(rng.choice([10, 0, 30])),
+    kw = dict(blockSize=bs, minDisparity=minD, uniquenessRatio=int(rng.choice([10, 0, 30, -1])),
               speckleWindowSize=int(rng.choice([100, 0, 15])), speckleRange=int(rng.choice([32, 1, 2])),
-              disp12MaxDiff=int(rng.choice([1, -1, 0])), P1=int(rng.choice([600, 8, 100])), P2=int(rng.choice([2400, 700, 3000])),
-              paths=int(rng.choice([8, 5])))
+              disp12MaxDiff=int(rng.choice([1, -1, 0, 2])), P1=int(rng.choice([600, 8, 100, 0])),
+              P2=int(rng.choice([2400, 700, 3000, 0])), paths=int(rng.choice([8, 5])))
     L, R = synth.make_pair(synth.STREAM_SEED + 7000 + seed, W, H, D)
     want = oracle.sgm_compute(L, R, numDisparities=D, **kw)
     m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, **kw)

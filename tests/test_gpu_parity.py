@@ -251,14 +251,16 @@ def test_morph_device_batch_and_timing_shape(pkg, oracle):
         assert np.array_equal(got[i], oracle.morph_open_close(masks[i])), i
 
 
-# ---- SGM-8 (BASELINE config 5) ---------------------------------------------------------------
-# Integer algorithm defined by oracle/sgm_oracle.c: the stated tolerance against that oracle is 0
-# (exact equality); against a real cv::StereoSGBM the comparison is unpinned.
+# ---- cv::StereoSGBM (rows S / f4; BASELINE config 5) ----------------------------------------------
+# Integer algorithm restated in oracle/sgm_oracle.c (MODE_SGBM = paths 5, MODE_HH = paths 8): the stated tolerance
+# against that oracle is 0 (exact equality); against a real cv::StereoSGBM the comparison is unpinned.
 @pytest.mark.parametrize("W,H,D,minD,bs", [(72, 28, 16, 0, 5), (200, 120, 32, 0, 5), (161, 75, 48, 0, 3), (150, 60, 32, 3, 5),
-                                           (150, 60, 32, -4, 5), (300, 100, 128, 0, 5), (96, 40, 16, 0, 7)])
+                                           (150, 60, 32, -4, 5), (300, 100, 128, 0, 5), (96, 40, 16, 0, 7), (180, 70, 32, 0, 13),
+                                           (140, 50, 16, 0, 17)])
 def test_sgm_matches_oracle(pkg, oracle, synth, W, H, D, minD, bs):
     L, R = synth.make_pair(synth.STREAM_SEED + 700 + W, W, H, D)
-    for kw in (dict(), dict(disp12MaxDiff=-1, speckleWindowSize=0), dict(uniquenessRatio=0, speckleWindowSize=30, speckleRange=2)):
+    for kw in (dict(), dict(paths=5), dict(disp12MaxDiff=-1, speckleWindowSize=0, paths=5),
+               dict(uniquenessRatio=0, speckleWindowSize=30, speckleRange=2)):
         m = pkg.HIPSemiGlobalMatcher(blockSize=bs, minDisparity=minD, numOfDisparities=D, width=W, height=H, **kw)
         got = m.compute(L, R)
         m.close()

@@ -1,6 +1,7 @@
-"""SGM-8 oracle (oracle/sgm_oracle.c, BASELINE config 5) against the independent numpy implementation,
-stage by stage.  PARITY UNPINNED against cv::StereoSGBM (the reference's SWSemiGlobalMatcher is a
-wrapper that main.cpp never instantiates); the algorithm checked here is the one sgm_oracle.c defines."""
+"""The cv::StereoSGBM restatement (oracle/sgm_oracle.c: MODE_SGBM = paths 5, what sgbm-sw.cpp:15 creates; MODE_HH =
+paths 8, BASELINE config 5) against the independent numpy implementation, stage by stage, plus known answers for the
+rules that are easy to get wrong (R1, R5, R7, R9, R10 of that file's header).  PARITY UNPINNED against the library
+itself: OpenCV is absent and the reference holds no fixtures."""
 import numpy as np
 import pytest
 
@@ -19,7 +20,9 @@ def test_volumes_match_bruteforce(oracle, synth, W, H, D, minD, bs):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(disp12MaxDiff=-1, speckleWindowSize=0), dict(uniquenessRatio=0),
-                                dict(minDisparity=2), dict(speckleWindowSize=20, speckleRange=2), dict(P1=8, P2=32)])
+                                dict(minDisparity=2), dict(minDisparity=-3), dict(speckleWindowSize=20, speckleRange=2),
+                                dict(P1=8, P2=32), dict(P1=0, P2=0), dict(uniquenessRatio=-1, disp12MaxDiff=3),
+                                dict(paths=5), dict(paths=5, blockSize=9), dict(paths=5, blockSize=13, speckleWindowSize=0)])
 def test_full_sgm_matches_bruteforce(oracle, synth, kw):
     L, R = synth.make_pair(synth.STREAM_SEED + 600, 72, 28, 16)
     a = oracle.sgm_compute(L, R, numDisparities=16, **kw)
@@ -58,7 +61,57 @@ def test_kat_constant_image_picks_disparity_zero(oracle):
 
 def test_parameter_validation(oracle, synth):
     L, R = synth.make_pair(synth.STREAM_SEED, 64, 20, 16)
-    for bad in (dict(numDisparities=20), dict(blockSize=4), dict(P1=0), dict(P1=10, P2=10), dict(uniquenessRatio=101)):
+    # blockSize 19: 93 * 19^2 + 2400 > 32767, where the library's 16-bit costs wrap (deviation (a) of sgm_oracle.c)
+    for bad in (dict(numDisparities=20), dict(blockSize=4), dict(uniquenessRatio=101), dict(blockSize=19)):
         kw = dict(numDisparities=16); kw.update(bad)
         with pytest.raises(ValueError):
             oracle.sgm_compute(L, R, **kw)
+    # R12: P1 <= 0 -> 2, P2 <= 0 -> 5, P2 >= P1 + 1: coerced, not refused
+    a = oracle.sgm_compute(L, R, numDisparities=16, P1=0, P2=0)
+    assert np.array_equal(a, oracle.sgm_compute(L, R, numDisparities=16, P1=2, P2=5))
+    assert np.array_equal(oracle.sgm_compute(L, R, numDisparities=16, P1=10, P2=10), oracle.sgm_compute(L, R, numDisparities=16, P1=10, P2=11))
+
+
+def test_kat_left_right_check_cannot_be_switched_off(oracle, synth):
+    # R9: disp12MaxDiff <= 0 means 1
+    L, R = synth.make_pair(synth.STREAM_SEED + 620, 96, 30, 16)
+    a = oracle.sgm_compute(L, R, numDisparities=16, disp12MaxDiff=-1)
+    assert np.array_equal(a, oracle.sgm_compute(L, R, numDisparities=16, disp12MaxDiff=0))
+    assert np.array_equal(a, oracle.sgm_compute(L, R, numDisparities=16, disp12MaxDiff=1))
+
+
+def test_kat_median_of_nine_with_replicated_border(oracle):
+    # R10: an isolated spike disappears, a 2-pixel-wide vertical bar survives, the corner uses the clamped neighbourhood
+    img = np.zeros((6, 8), np.int16)
+    img[3, 3] = 500
+    img[:, 6:8] = 77
+    img[0, 0] = -16
+    out = oracle.median3x3(img)
+    assert out[3, 3] == 0 and (out[:, 6:8] == 77).all() and out[0, 0] == 0
+    col = np.arange(12, dtype=np.int16).reshape(12, 1) * 16
+    assert np.array_equal(oracle.median3x3(col), col)            # a single column: median of three replicated triples
+    rng = np.random.default_rng(5)
+    big = rng.integers(-16, 2000, (37, 53)).astype(np.int16)
+    assert np.array_equal(oracle.median3x3(big), bf.median3x3(big).astype(np.int16))
+
+
+def test_kat_raw_border_columns_are_ftzero(oracle):
+    # R1: with flat gradients (constant rows) the only cost comes from the raw intensities; a left pixel in the LAST column
+    # is compared as if its intensity were 15
+    W, H, D = 40, 6, 16
+    L = np.full((H, W), 200, np.uint8); R = np.full((H, W), 200, np.uint8)
+    pix, _, _ = oracle.sgm_stages(L, R, numDisparities=D)
+    assert (pix[:, :-1, :] == 0).all()                           # interior: identical intensities
+    # x = W-1: u = 15 with half-way points (15+200)//2 = 107 towards the left neighbour; v = 200: cost min(200-107, ...) >> 2
+    assert (pix[:, -1, 1:] == ((200 - 107) >> 2)).all()
+    assert (pix[:, -1, 0] == 0).all()                            # d = 0: the right pixel is column W-1 as well, also 15
+
+
+def test_kat_sums_saturate_at_short_max(oracle):
+    # R5: S = min(sum of the path costs, 32767)
+    C = np.full((4, 5, 16), 9000, np.uint16)
+    import ctypes as Ct
+    S = np.zeros_like(C)
+    oracle.lib().orc_sgm_aggregate_paths(C.ctypes.data_as(Ct.POINTER(Ct.c_uint16)), 5, 4, 16, 600, 2400, 5,
+                                          S.ctypes.data_as(Ct.POINTER(Ct.c_uint16)))
+    assert (S == 32767).all()                                    # five paths of >= 9000 each
