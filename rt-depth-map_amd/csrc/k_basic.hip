@@ -319,8 +319,8 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = g.W, INV = g.filtered;
     const int Wp = (W + 7) & ~7;                                      // LDS rows hold whole 8-column chunks
-    uint32_t* key = (uint32_t*)smem;                                  // Wp keys: cost << 16 | x
-    int16_t* snap = (int16_t*)(key + Wp);                             // Wp: the row before the check
+    uint32_t* key = (uint32_t*)smem;                                  // Wp keys: cost << 16 | x, + the spare slot key[Wp]
+    int16_t* snap = (int16_t*)(key + Wp + 4);                         // Wp: the row before the check
     int16_t* fin = snap + Wp;                                         // Wp: the row after it (SPK)
     __shared__ int wsum[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -350,33 +350,49 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
         const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
         ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
     }
+    if (tid == 0) key[Wp] = ~0u;
     __syncthreads();
-    {
+    // Votes and look-ups are straight-line code for all eight columns: a column that may not vote (or whose target lies
+    // outside the row) votes into the spare slot key[Wp], a look-up outside the row reads that slot too (it holds a vote
+    // nobody uses, or ~0).  Per-column branches cost more in exec-mask bookkeeping than the work they skip.
+    if (active) {
         const unsigned vm = im & votem;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (!((vm >> k) & 1)) continue;
             const int x = x0 + k, d = d8.v[k];
             const int x2 = x - ((d + 8) >> 4);
-            if ((unsigned)x2 >= (unsigned)W) continue;
-            atomicMin(&key[x2], ((uint32_t)(uint16_t)c8.v[k] << 16) | (uint32_t)x);
+            const bool ok = ((vm >> k) & 1) && (unsigned)x2 < (unsigned)W;
+            atomicMin(&key[ok ? x2 : Wp], ((uint32_t)(uint16_t)c8.v[k] << 16) | (uint32_t)x);
         }
     }
     __syncthreads();
     if (active) {
         const unsigned chk = im & votem & keepm;                      // columns whose two matches are looked up
         unsigned kill = im & ~keepm;                                  // outside the valid rectangle: always dropped
+        unsigned bad0m = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            if (!((chk >> k) & 1)) continue;
             const int x = x0 + k, d = d8.v[k];
-            const int xa = x - (d >> 4), xb = x - ((d + 15) >> 4);
-            bool bad0 = false, bad1 = false;
-            if ((unsigned)xa < (unsigned)W) { const uint32_t q = key[xa]; if (q != ~0u) bad0 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
-            // a pixel dies only if BOTH matches disagree: the second look-up is needed by the lanes whose first one did
-            // (consistent regions: none of the wave's lanes)
-            if (bad0 && (unsigned)xb < (unsigned)W) { const uint32_t q = key[xb]; if (q != ~0u) bad1 = abs((int)snap[q & 0xffff] - d) > maxDiff16; }
-            kill |= (unsigned)(bad0 && bad1) << k;
+            const int xa = x - (d >> 4);
+            const bool in = ((chk >> k) & 1) && (unsigned)xa < (unsigned)W;
+            const uint32_t q = key[in ? xa : Wp];
+            int dv = snap[min(q & 0xffffu, (uint32_t)(Wp - 1))];
+            asm volatile("" : "+v"(dv));                              // keep the read unconditional (no branch around it)
+            bad0m |= ((unsigned)in & (unsigned)(q != ~0u) & (unsigned)(abs(dv - d) > maxDiff16)) << k;
+        }
+        // a pixel dies only if BOTH matches disagree: the second look-ups are needed only where the first ones did
+        // (consistent regions: by none of the wave's lanes)
+        if (__builtin_amdgcn_ballot_w64(bad0m != 0) != 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int x = x0 + k, d = d8.v[k];
+                const int xb = x - ((d + 15) >> 4);
+                const bool in = ((bad0m >> k) & 1) && (unsigned)xb < (unsigned)W;
+                const uint32_t q = key[in ? xb : Wp];
+                int dv = snap[min(q & 0xffffu, (uint32_t)(Wp - 1))];
+                asm volatile("" : "+v"(dv));
+                kill |= ((unsigned)in & (unsigned)(q != ~0u) & (unsigned)(abs(dv - d) > maxDiff16)) << k;
+            }
         }
         if (kill) {
 #pragma unroll
@@ -403,15 +419,17 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     const unsigned hm = im & ~cb & 0xffu;                             // run heads
     unsigned lm = im & ~(cb >> 1) & 0xffu;                            // run ends
     const int agg = hm ? ((__builtin_popcount(hm) << 16) | (x0 + (31 - __builtin_clz(hm)) + 1)) : 0;
+    // inclusive wave scan with DPP row shifts / row broadcasts (a __shfl_up chain is six dependent LDS-crossbar round
+    // trips); lanes without a source get the identity 0
     int t = agg;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int u = __shfl_up(t, o);
-        if (lane >= o) t = OpHead::f(t, u);
-    }
+#define RTDM_SCAN(ctrl, rmask) t = OpHead::f(t, __builtin_amdgcn_update_dpp(0, t, ctrl, rmask, 0xf, false))
+    RTDM_SCAN(0x111, 0xf); RTDM_SCAN(0x112, 0xf); RTDM_SCAN(0x114, 0xf); RTDM_SCAN(0x118, 0xf);   // row_shr:1,2,4,8
+    RTDM_SCAN(0x142, 0xa);                                                                          // row_bcast:15
+    RTDM_SCAN(0x143, 0xc);                                                                          // row_bcast:31
+#undef RTDM_SCAN
     if (lane == 63) wsum[wv] = t;
     __syncthreads();
-    int run = __shfl_up(t, 1);
+    int run = __builtin_amdgcn_update_dpp(0, t, 0x138, 0xf, 0xf, false);                           // wave_shr:1
     if (lane == 0) run = 0;
     for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[q]);
     if (!active) return;
@@ -456,7 +474,7 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
                      (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2) | (size_t)cost | (size_t)headmap) & 15) == 0;
     if (vec) {
         const dim3 vblock((unsigned)(((Wp >> 3) + 63) & ~63));
-        const size_t lds = (size_t)Wp * 8;
+        const size_t lds = (size_t)Wp * 8 + 16;
         if (label) hipLaunchKernelGGL(k_lrcheck_vec<true>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
         else       hipLaunchKernelGGL(k_lrcheck_vec<false>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
     } else if (label) {
@@ -573,9 +591,12 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
 // Strip form of the merge for aligned rows: one thread walks RS consecutive row pairs of its 8 columns, so every
 // row of disparities / heads is loaded once instead of twice (as the lower row of one pair and the upper row of the
 // next).  Same unions as k_spk_merge<true> with ystep = 1.
+// size / maxSize: a contact between two runs that are EACH longer than maxSize needs no union -- both components are
+// "large" whatever else they touch, and only "size <= maxSize" is ever asked (exact; it removes most unions: disparity
+// maps are made of long runs).  size[] still holds the run lengths here (k_spk_count runs afterwards).
 template <int RS>
 __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int Ws, int H,
-                                                         int y_lo, int npairs, int newVal, int maxDiff)
+                                                         int y_lo, int npairs, int newVal, int maxDiff, const int32_t* size, int maxSize)
 {
     // contacts found by the 256 threads are queued in LDS and united afterwards by the first threads, one union per
     // lane: a union is a chain of dependent global accesses, and a wave with a single busy lane stalls as long as a full one
@@ -644,7 +665,11 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     }
     __syncthreads();
     const int total = min(qn, QCAP);
-    for (int i = threadIdx.x; i < total; i += 256) uf_union(label, queue[i].x, queue[i].y);
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int a = queue[i].x, b = queue[i].y;
+        if (size[a] > maxSize && size[b] > maxSize) continue;         // two large runs: nothing to learn from uniting them
+        uf_union(label, a, b);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, const uint32_t* runs,
@@ -675,6 +700,7 @@ __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t*
     for (int i = threadIdx.x & 15; i < cnt; i += 16) {
         const uint32_t rn = runs[base + i];
         const int x = (int)(rn & 0xffffu), len = (int)(rn >> 16);
+        if (len > maxSize) continue;               // a run longer than the limit is in a large component by itself
         // after k_spk_count a head is at most a couple of hops from its root (a late path-halving
         // store of another thread may have left an ancestor instead of the root), so chase it
         int root = base + x;
@@ -712,8 +738,8 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         if (vec && step == 1 && rs > 1) {
             const int RSV = rs >= 8 ? 8 : 4;
             dim3 sgrid((nxb * ((npairs + RSV - 1) / RSV) + 255) / 256, n);
-            if (RSV == 8) hipLaunchKernelGGL(k_spk_merge_strip<8>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff);
-            else          hipLaunchKernelGGL(k_spk_merge_strip<4>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff);
+            if (RSV == 8) hipLaunchKernelGGL(k_spk_merge_strip<8>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
+            else          hipLaunchKernelGGL(k_spk_merge_strip<4>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
         } else
         if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
