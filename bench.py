@@ -77,10 +77,18 @@ def launch_ranks(n):
     sys.exit(rc)
 
 
+def oracle_ready(rank, dist):
+    """Build the oracle library once per job (rank 0; the others wait): concurrent builds would race on the same file."""
+    from oracle import oracle as orc
+    if rank == 0:
+        orc.build()
+    if dist is not None:
+        dist.barrier()
+
+
 def oracle_frames(dL, dR, idx, threads):
     """The CPU oracle's disparity for frames idx of the device batch (the checker, never the thing measured)."""
     from oracle import oracle as orc
-    orc.build()
     return [orc.bm_compute(dL[i].cpu().numpy(), dR[i].cpu().numpy(), nthreads=threads, numDisparities=D, blockSize=BLOCK)
             for i in idx]
 
@@ -157,6 +165,7 @@ def rccl_stream(args, pkg, torch, dist, rank, local_rank, world, backend):
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
     rc = 0
+    oracle_ready(rank, dist)
     if rank == 0:
         idx = sorted({0, N // 2, N - 1})
         want = oracle_frames(left, right, idx, min(os.cpu_count() or 1, 64))
@@ -263,6 +272,7 @@ def main():
     # parity self-check of the timed path (this batch size, autotuned strips, side-stream border kernel): three frames of
     # the last step's output against the CPU oracle, on every rank's own shard
     import numpy as np
+    oracle_ready(rank, dist)
     idx = sorted({0, B // 2, B - 1})
     want = oracle_frames(dL, dR, idx, max(1, min((os.cpu_count() or 1) // max(1, min(world, torch.cuda.device_count())), 64)))
     bad = [i for i, w in zip(idx, want) if not np.array_equal(dD[i].cpu().numpy(), w)]

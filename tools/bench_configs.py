@@ -14,13 +14,13 @@ CONFIGS = [
     ("config1 320x240 d=32 7x7", 320, 240, 32, 7, 256, None),
     ("config1 233x156 ROI crop of 320x240 d=32 7x7", 233, 156, 32, 7, 256, None),
     ("config2 640x480 d=64 9x9", 640, 480, 64, 9, 128, None),
-    ("headline 1280x720 d=64 9x9", 1280, 720, 64, 9, 64, None),
+    ("headline 1280x720 d=64 9x9", 1280, 720, 64, 9, 256, None),
     ("headline + ROI1 = 400x300 box (estimator.cpp:54)", 1280, 720, 64, 9, 64, (440, 210, 400, 300)),
     ("config3 1280x720 d=128 11x11", 1280, 720, 128, 11, 32, None),
     ("reference default 1280x720 d=192 13x13", 1280, 720, 192, 13, 32, None),
 ]
 out = []
-cores = min(os.cpu_count() or 1, 16)
+cores = min(os.cpu_count() or 1, 64)
 for name, W, H, D, w, B, roi in CONFIGS:
     dL = torch.empty((B, H, W), dtype=torch.uint8, device="cuda"); dR = torch.empty_like(dL)
     dD = torch.empty((B, H, W), dtype=torch.int16, device="cuda")

@@ -1,12 +1,13 @@
 #!/bin/bash
 # HBM traffic and SQ activity of the hot-path kernels (run on the GPU box).  Counters are collected in passes of
 # their own (no tracing domains): FETCH_SIZE and WRITE_SIZE cannot share a pass; the SQ set fills its 8 slots.
-# Writes gpurun_out/pmc_traffic/{summary.txt,traffic.json}; copy them to profiles/rNN_pmc_traffic_rocprofv3.txt / .json.
+# Writes gpurun_out/pmc_traffic/{summary.txt,traffic.json}; tools/pmc_finalize.py copies them to profiles/rNN_pmc_traffic*
+# and adds the git commit.  traffic.json records the hash of the device sources it was measured on (bench.py compares).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
-B="--steps 2 --warmup 1 --batch 64 --no-cpu-baseline"
+B="--steps 2 --warmup 2 --batch 256 --no-cpu-baseline"    # the bench's own batch; warm-up 2: the second call measures the strip count
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- $R/tools/ubench_fetch > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $R/tools/ubench_fetch > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_fetch -- python $R/bench.py $B > /dev/null 2>&1
@@ -14,7 +15,9 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/bench_write -- python $R/
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
     --output-format csv -d $OUT/bench_sq -- python $R/bench.py $B > /dev/null 2>&1
 python - <<PY
-import csv, glob, collections, json, re
+import csv, glob, collections, json, re, sys
+sys.path.insert(0, "$R")
+import bench as _bench
 def load(d):
     agg = collections.defaultdict(list)
     for f in glob.glob("$OUT/" + d + "/*/*counter_collection.csv"):
@@ -33,8 +36,8 @@ for d in ("cal_fetch", "cal_write", "bench_fetch", "bench_write", "bench_sq"):
                 key = re.sub(r"^void ", "", k).replace("rtdm::", "").replace(", ", ",")
                 data.setdefault(key, {})[c] = sum(v) / len(v)
 open("$OUT/summary.txt", "w").write("\n".join(lines) + "\n")
-PAIRS = 64
-out = {"source": "tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes)", "pairs_per_launch": PAIRS, "workload": "1280x720 d=64 9x9",
+PAIRS = 256
+out = {"kernel_source_sha": _bench.kernel_source_sha(), "source": "tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes)", "pairs_per_launch": PAIRS, "workload": "1280x720 d=64 9x9",
        "fetch_correction": 2.0, "unit": "KB (FETCH_SIZE reads 1/2 on gfx950, calibrated with tools/ubench_fetch; WRITE_SIZE exact)",
        "sq_unit": "quad-cycles summed over all waves / SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs", "kernels": {}}
 for k, c in sorted(data.items()):
@@ -44,7 +47,10 @@ for k, c in sorted(data.items()):
     if "SQ_ACTIVE_INST_VALU" in c and c.get("GRBM_GUI_ACTIVE"):
         # SIMD-cycles available = clocks x 256 CUs x 4 SIMDs; a VALU instruction occupies its SIMD for the counted quad-cycles x 4
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8 * 256 * 4
-        e["valu_busy_frac_of_simd_cycles"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles, 4)
+        # SQ_ACTIVE_INST_VALU counts quad-cycles; short dispatches read GRBM_GUI_ACTIVE high (MI355X_MICROARCH.md, DVFS
+        # give-back), so the fraction is good to about +-5 % and is clamped to 1
+        e["valu_busy_frac_of_simd_cycles"] = round(min(1.0, c["SQ_ACTIVE_INST_VALU"] * 4 / simd_cycles), 4)
+        e["valu_busy_error_bar"] = 0.05
         e["valu_insts_per_pixel"] = round(c["SQ_INSTS_VALU"] * 64 / (PAIRS * 1280 * 720), 1) if "SQ_INSTS_VALU" in c else None
         if c.get("SQ_WAVE_CYCLES"):
             e["wave_cycle_split"] = {n: round(c.get(n, 0) / c["SQ_WAVE_CYCLES"], 4) for n in ("SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY")}
