@@ -11,35 +11,19 @@
 //   * vertical: sliding window down the strip.  The entering row accumulates straight into the
 //     running sums (the quad-SAD's accumulator operand); the leaving row is recomputed from the
 //     LDS ring and subtracted with v_pk_sub_u16.
-//   * selection per output pixel, all in registers and in two levels: packed minima of groups of eight
-//     disparities (v_pk_min_u16), 32-bit keys (min << 8 | group) built by v_perm and reduced with v_min3_u32
-//     give (minsad, first group), the six registers around that group come out of a v_cndmask tree and the
-//     eight in-group keys (sad << 8 | e) give the FIRST argmin; uniqueness is the identity
-//       sum_e max(T+1 - sad[e], 0)  ==  the same sum over {mind-1, mind, mind+1}
-//     evaluated with saturating packed u16 ops (groups above the threshold in the whole wave are skipped);
-//     sad[mind +- 1] are among the six fetched registers.
+//   * selection per output pixel, all in registers: rtdm_select.h (shared with k_search_ring).
 //   * launch: 1-D grid, XCD-aware (see FastGeom); row strips per frame from a cost model, measured once per
 //     batch shape by the caller (rtdm_api.hip, tune_strips).
 //   Only columns whose whole window is free of border clamping are handled here; the 2*(w/2)
 //   border columns are searched by extra workgroups of the same grid (rtdm_border.h; they are outside the
 //   valid rectangle but feed the left-right check).  Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
 #include "rtdm_border.h"
+#include "rtdm_select.h"
 
 #include <cmath>
 #include <cstdlib>
 
 namespace rtdm {
-
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
-{ return __builtin_bit_cast(uint32_t, (us2)(__builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b))); }
-__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b)
-{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
-__device__ __forceinline__ uint32_t pk_sub_sat(uint32_t a, uint32_t b)
-{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
-__device__ __forceinline__ uint32_t pk_add_sat(uint32_t a, uint32_t b)
-{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b))); }
 
 struct FastGeom {
     int x0, nx;          // output-column range [x0, x0+nx) handled by this kernel
@@ -104,18 +88,6 @@ __device__ __forceinline__ void left_pieces(const uint32_t* __restrict__ lp, uin
 #pragma unroll
     for (int k = 0; k < NP - 1; ++k) tacc = __builtin_amdgcn_sad_u8(l[k], capb, tacc);
     tacc = __builtin_amdgcn_msad_u8(capb, l[NP - 1], tacc);   // zero bytes of the reference are skipped
-}
-
-__device__ __forceinline__ int div_trunc_small(int num, int den)   // den > 0, |num| < 2^24
-{
-    const unsigned an = (unsigned)(num < 0 ? -num : num);
-    unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
-    int rem = (int)an - (int)(q * (unsigned)den);
-    if (rem < 0) { --q; rem += den; }
-    if (rem < 0) { --q; rem += den; }
-    if (rem >= den) { ++q; rem -= den; }
-    if (rem >= den) { ++q; }
-    return num < 0 ? -(int)q : (int)q;
 }
 
 template <int D, int NP>
@@ -240,8 +212,10 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
                 else               row_sads<D, NP, (NG > 48 ? 48 : 0), CG>(l, lds + ri, T);
 #pragma unroll
                 for (int i = 0; i < CG; ++i) {
-                    const uint32_t lo = pk_sub((uint32_t)S[c0 + i], (uint32_t)T[i]);
-                    const uint32_t hi = pk_sub((uint32_t)(S[c0 + i] >> 32), (uint32_t)(T[i] >> 32));
+                    // plain 32-bit subtractions of the packed pairs (v_sub_u32 issues 1.6x faster than v_pk_sub_u16): each
+                    // half of the window sum is >= that half of the leaving row's sum, so no borrow crosses the halves
+                    const uint32_t lo = (uint32_t)S[c0 + i] - (uint32_t)T[i];
+                    const uint32_t hi = (uint32_t)(S[c0 + i] >> 32) - (uint32_t)(T[i] >> 32);
                     S[c0 + i] = (uint64_t)lo | ((uint64_t)hi << 32);
                 }
             }
@@ -260,111 +234,9 @@ __global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane
             uint32_t rr[NR];
 #pragma unroll
             for (int i = 0; i < NG; ++i) { rr[2 * i] = (uint32_t)S[i]; rr[2 * i + 1] = (uint32_t)(S[i] >> 32); }
-            // (minsad, FIRST argmin) in two levels.  Level 1: packed minima of groups of four registers (eight
-            // disparities): v_pk_min_u16 serves two values per instruction and needs no key.  Level 2: keys
-            // min << 8 | group over the 2 NGp half-group minima -> (minsad, first group that holds it).  Level 3: the six
-            // registers around that group are fetched (they also hold sad[a-1] and sad[a+1]) and the eight in-group
-            // keys sad << 8 | e give the first e.  Ties: the smallest e lies in the smallest group that attains the
-            // minimum, and level 3 takes the smallest e inside it.
-            constexpr int NGp = NR / 4;
-            uint32_t kacc[2] = {0xffffffffu, 0xffffffffu};   // two chains: no back-to-back dependency
-            uint32_t gmin[NGp];                               // kept: the uniqueness test skips groups above its threshold
-#pragma unroll
-            for (int gq = 0; gq < NGp; ++gq) {
-                const uint32_t gm = pk_min(pk_min(rr[4 * gq], rr[4 * gq + 1]), pk_min(rr[4 * gq + 2], rr[4 * gq + 3]));
-                gmin[gq] = gm;
-                const uint32_t gc = (uint32_t)gq | ((uint32_t)gq << 8);
-                const uint32_t klo = __builtin_amdgcn_perm(gm, gc, 0x0C050400u);
-                const uint32_t khi = __builtin_amdgcn_perm(gm, gc, 0x0C070601u);
-                kacc[gq & 1] = min(min(kacc[gq & 1], klo), khi);
-            }
-            const uint32_t kmin = min(kacc[0], kacc[1]);
-            const int m1 = (int)(kmin >> 8);
-            const int gs = (int)(kmin & 0xffu);
-            // six[k] = rr[4 gs - 1 + k], k = 0..5 (0 outside the array): binary select on the bits of gs
-            uint32_t six[6];
-            {
-                uint32_t cand[6][NGp];
-#pragma unroll
-                for (int k = 0; k < 6; ++k)
-#pragma unroll
-                    for (int gq = 0; gq < NGp; ++gq) {
-                        const int idx = 4 * gq - 1 + k;
-                        cand[k][gq] = (idx >= 0 && idx < NR) ? rr[idx] : 0u;
-                    }
-                constexpr int HBG = (NGp - 1) >= 16 ? 16 : (NGp - 1) >= 8 ? 8 : (NGp - 1) >= 4 ? 4 : (NGp - 1) >= 2 ? 2 : 1;
-                int len = NGp;
-#pragma unroll
-                for (int bit = HBG; bit >= 1; bit >>= 1) {
-                    const bool up = (gs & bit) != 0;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k)
-#pragma unroll
-                        for (int i = 0; i < bit; ++i)
-                            if (i < len) cand[k][i] = up ? ((i + bit < len) ? cand[k][i + bit] : 0u) : cand[k][i];
-                    len = bit < len ? bit : len;
-                }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) six[k] = cand[k][0];
-            }
-            uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
-                const uint32_t klo = __builtin_amdgcn_perm(six[1 + q], ec, 0x0C050400u);
-                const uint32_t khi = __builtin_amdgcn_perm(six[1 + q], ec, 0x0C070601u);
-                k3[q & 1] = min(min(k3[q & 1], klo), khi);
-            }
-            const int a = 8 * gs + (int)(min(k3[0], k3[1]) & 0xffu);
-            // the two packed registers that hold sad[a-1 .. a+1] are among the six
-            const int am1 = a > 0 ? a - 1 : 0;
-            const int jl = (am1 >> 1) - (4 * gs - 1);                 // 0..4
-            const bool j1 = (jl & 1) != 0, j2 = (jl & 2) != 0, j4 = (jl & 4) != 0;
-            const uint32_t e0 = j4 ? six[4] : (j2 ? (j1 ? six[3] : six[2]) : (j1 ? six[1] : six[0]));
-            const uint32_t e1 = j4 ? six[5] : (j2 ? (j1 ? six[4] : six[3]) : (j1 ? six[2] : six[1]));
-            const int posc = a > 0 ? (am1 & 1) + 1 : 0;         // position of sad[a] among the 4 fetched
-            const auto elem = [&](int pos) -> int {
-                return (int)__builtin_amdgcn_perm(e1, e0, 0x0C0C0100u + 0x0202u * (uint32_t)pos);
-            };
-            const bool has_n = a > 0, has_p = a + 1 < D;
-            const int n_real = elem(has_n ? posc - 1 : 0);
-            const int p_real = elem(has_p ? posc + 1 : 0);
-            bool fail = (int)tsum < g.tex;
-            if (g.uniq > 0) {
-                uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
-                T = min(T, 32766u);
-                const uint32_t T1 = T + 1u, T1pk = T1 * 0x00010001u;
-                // saturating sums of non-negative terms are order independent: four chains
-                // (the empty asm pins "four subtractions, then four additions": back-to-back dependent
-                //  packed ops cost a wait state each on gfx950)
-                uint32_t zz[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < NR; i += 4) {
-                    // a group none of whose eight values reaches the threshold in any lane adds nothing (exact)
-                    if (__builtin_amdgcn_ballot_w64(pk_sub_sat(T1pk, gmin[i >> 2]) != 0u) == 0) continue;
-                    uint32_t t0 = pk_sub_sat(T1pk, rr[i]), t1 = pk_sub_sat(T1pk, rr[i + 1]);
-                    uint32_t t2 = pk_sub_sat(T1pk, rr[i + 2]), t3 = pk_sub_sat(T1pk, rr[i + 3]);
-                    asm volatile("" : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
-                    zz[0] = pk_add_sat(zz[0], t0); zz[1] = pk_add_sat(zz[1], t1);
-                    zz[2] = pk_add_sat(zz[2], t2); zz[3] = pk_add_sat(zz[3], t3);
-                }
-                const uint32_t z = pk_add_sat(pk_add_sat(zz[0], zz[1]), pk_add_sat(zz[2], zz[3]));
-                const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
-                const uint32_t wsame = term(m1);
-                const uint32_t wother = (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
-                const uint32_t zlo = z & 0xffffu, zhi = z >> 16;
-                const bool even = (a & 1) == 0;
-                fail |= (even ? zlo : zhi) != wsame;
-                fail |= (even ? zhi : zlo) != wother;
-            }
-            int out = g.filtered;
-            if (!fail) {
-                const int pp = has_p ? p_real : n_real;
-                const int nn = has_n ? n_real : p_real;
-                const int den = pp + nn - 2 * m1 + abs(pp - nn);
-                const int q = den != 0 ? div_trunc_small((pp - nn) * 256, den) : 0;
-                out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
-            }
+            // (minsad, FIRST argmin), uniqueness, sub-pixel: rtdm_select.h (shared with k_search_ring)
+            int m1; bool fail;
+            const int out = select_disparity<D>(rr, (int)tsum, g, &m1, &fail);
             if (active) {
                 if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)m1;
                 db[(size_t)y * disp.pitch_e + col] = (int16_t)(masked_col ? g.filtered : out);

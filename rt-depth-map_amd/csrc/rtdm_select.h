@@ -41,7 +41,8 @@ __device__ __forceinline__ int sel_div_trunc(int num, int den)   // den > 0, |nu
 }
 
 // Returns the x16 disparity (g.filtered if rejected); *minsad = the winning SAD, *rejected = the pixel failed a test.
-template <int D>
+// SEQ_TREES: build the six fetch trees one after the other (fewer live registers, less instruction-level parallelism).
+template <int D, bool SEQ_TREES = (D >= 96)>
 __device__ __forceinline__ int select_disparity(const uint32_t (&rr)[D / 2], int tsum, const BMGeom& g, int* minsad, bool* rejected)
 {
     constexpr int NR = D / 2, NGp = NR / 4;
@@ -59,31 +60,32 @@ __device__ __forceinline__ int select_disparity(const uint32_t (&rr)[D / 2], int
     const uint32_t kmin = min(kacc[0], kacc[1]);
     const int m1 = (int)(kmin >> 8);
     const int gs = (int)(kmin & 0xffu);
-    // six[k] = rr[4 gs - 1 + k], k = 0..5 (0 outside the array): binary select on the bits of gs
+    // six[k] = rr[4 gs - 1 + k], k = 0..5 (0 outside the array): binary select on the bits of gs.  One output at a time
+    // (the empty asm keeps the trees from being interleaved): interleaved, the six trees keep 6 * NGp/2 temporaries alive
+    // next to the D/2 SAD registers, which is what pushed D = 128 over 128 VGPRs.
     uint32_t six[6];
     {
-        uint32_t cand[6][NGp];
+        constexpr int HBG = (NGp - 1) >= 16 ? 16 : (NGp - 1) >= 8 ? 8 : (NGp - 1) >= 4 ? 4 : (NGp - 1) >= 2 ? 2 : 1;
 #pragma unroll
-        for (int k = 0; k < 6; ++k)
+        for (int k = 0; k < 6; ++k) {
+            uint32_t cand[NGp];
 #pragma unroll
             for (int gq = 0; gq < NGp; ++gq) {
                 const int idx = 4 * gq - 1 + k;
-                cand[k][gq] = (idx >= 0 && idx < NR) ? rr[idx] : 0u;
+                cand[gq] = (idx >= 0 && idx < NR) ? rr[idx] : 0u;
             }
-        constexpr int HBG = (NGp - 1) >= 16 ? 16 : (NGp - 1) >= 8 ? 8 : (NGp - 1) >= 4 ? 4 : (NGp - 1) >= 2 ? 2 : 1;
-        int len = NGp;
+            int len = NGp;
 #pragma unroll
-        for (int bit = HBG; bit >= 1; bit >>= 1) {
-            const bool up = (gs & bit) != 0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k)
+            for (int bit = HBG; bit >= 1; bit >>= 1) {
+                const bool up = (gs & bit) != 0;
 #pragma unroll
                 for (int i = 0; i < bit; ++i)
-                    if (i < len) cand[k][i] = up ? ((i + bit < len) ? cand[k][i + bit] : 0u) : cand[k][i];
-            len = bit < len ? bit : len;
+                    if (i < len) cand[i] = up ? ((i + bit < len) ? cand[i + bit] : 0u) : cand[i];
+                len = bit < len ? bit : len;
+            }
+            six[k] = cand[0];
+            if (SEQ_TREES) asm volatile("" : "+v"(six[k]));
         }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) six[k] = cand[k][0];
     }
     uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
 #pragma unroll

@@ -51,3 +51,42 @@ def test_adapter_keeps_the_reference_constructor_shape():
     assert pos == sorted(pos)
     assert "public BlockMatcher" in text
     assert "public VideoFilterDevice" in open(os.path.join(HOST, "mf-hip.h")).read()
+
+
+@pytest.mark.skipif(not os.path.isdir(REF) or not os.path.exists("/opt/rocm/bin/hipcc"),
+                    reason="needs the reference tree (build container only) and hipcc")
+def test_makefile_build_hip_rule_compiles_a_kernel_under_the_reference_kbuild(tmp_path):
+    """north_star: "Makefile.build extended".  The reference's own Makefile.build / Makefile.include are taken as they
+    lie in /root/reference (copied into a scratch directory at test time, never into the repository), the HIP rule of
+    host/Makefile.build.hip-rule is inserted behind the .cpp pattern rule, and the reference's per-directory protocol
+    (`make -f Makefile.build obj=<dir>/ _all` with `obj-y` in <dir>/Makefile, Makefile:7 / stereo-matcher/Makefile:1) builds
+    one of this repository's kernels with it.  The full application cannot be linked here (no OpenCV)."""
+    text = open(os.path.join(REF, "Makefile.build")).read()
+    rule = open(os.path.join(HOST, "Makefile.build.hip-rule")).read()
+    marker = "$(obj)%.d : ;"
+    assert marker in text
+    (tmp_path / "Makefile.build").write_text(text.replace(marker, rule + "\n" + marker))
+    shutil.copy(os.path.join(REF, "Makefile.include"), tmp_path / "Makefile.include")
+    mod = tmp_path / "hip-matcher"
+    mod.mkdir()
+    (mod / "Makefile").write_text("obj-y += k_synth.o\n")
+    csrc = os.path.join(ROOT, "rt-depth-map_amd", "csrc")
+    shutil.copy(os.path.join(csrc, "k_synth.hip"), mod / "k_synth.hip")
+    inc = tmp_path / "include"
+    inc.mkdir()
+    shutil.copy(os.path.join(csrc, "rtdm_kernels.h"), inc / "rtdm_kernels.h")
+    src = (mod / "k_synth.hip").read_text().replace('#include "rtdm_kernels.h"', '#include <rtdm_kernels.h>')
+    (mod / "k_synth.hip").write_text(src)
+    dry = subprocess.run(["make", "-n", "-f", "Makefile.build", "obj=hip-matcher/", "_all"], cwd=tmp_path, capture_output=True, text=True)
+    assert dry.returncode == 0, dry.stderr
+    assert "hipcc" in dry.stdout and "--offload-arch=gfx950" in dry.stdout and "hip-matcher/k_synth.hip" in dry.stdout
+    run = subprocess.run(["make", "-f", "Makefile.build", "obj=hip-matcher/", "_all"], cwd=tmp_path, capture_output=True, text=True)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "[HIPCC] hip-matcher/k_synth.hip" in run.stdout
+    assert (mod / "k_synth.o").stat().st_size > 1000
+    # the .cpp rule is untouched: a host file in the same directory still goes to $(CC)
+    (mod / "Makefile").write_text("obj-y += k_synth.o glue.o\n")
+    (mod / "glue.cpp").write_text("int rtdm_glue() { return 0; }\n")
+    dry = subprocess.run(["make", "-n", "-f", "Makefile.build", "obj=hip-matcher/", "_all", "CC=g++", "CFLAGS=-O2"], cwd=tmp_path,
+                         capture_output=True, text=True)
+    assert dry.returncode == 0 and "g++ -O2 -c hip-matcher/glue.cpp" in dry.stdout, dry.stdout + dry.stderr
