@@ -90,8 +90,12 @@ __device__ __forceinline__ void left_pieces(const uint32_t* __restrict__ lp, uin
     tacc = __builtin_amdgcn_msad_u8(capb, l[NP - 1], tacc);   // zero bytes of the reference are skipped
 }
 
+#ifndef FAST_TIGHT_BOUNDS     // 1: register budgets one occupancy step tighter for D >= 128 (A/B: tools/fast_ab.sh)
+#define FAST_TIGHT_BOUNDS 0
+#endif
+
 template <int D, int NP>
-__global__ __launch_bounds__(256) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
+__global__ __launch_bounds__(256, (FAST_TIGHT_BOUNDS ? (D >= 192 ? 3 : D >= 128 ? 4 : 1) : 1)) void k_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
                                                      BMGeom g, FastGeom fg, BorderGeom bg)
 {
     using C = FastCfg<D, NP>;

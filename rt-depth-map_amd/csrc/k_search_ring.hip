@@ -434,10 +434,14 @@ static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
     rg.nitems = (unsigned)tiles * strips * n;
     static const size_t ldspad = [] { const char* e = getenv("RTDM_RING_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
     const size_t ldsb = (size_t)4 * C::WAVE_LDS * sizeof(uint32_t) + ldspad;   // (padding: occupancy experiments)
-    static bool attr_set = false;
-    if (!attr_set && ldsb > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        attr_set = true;
+    if (ldsb > 48 * 1024) {                         // once per device of this process (a handle lives on one device)
+        static unsigned long long done = 0;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 64 || !((done >> dev) & 1)) {
+            (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            if (dev < 64) done |= 1ull << dev;
+        }
     }
     hipLaunchKernelGGL((k_search_ring<D, WS>), dim3(rg.nitems), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg);
 }
