@@ -72,3 +72,21 @@ def test_partition_is_a_contiguous_cover():
             for (s0, c0), (s1, _) in zip(spans, spans[1:]):
                 assert s0 + c0 == s1
     assert sh.shard_sizes(1024, 8) == [128] * 8
+
+
+def test_bench_launcher_relays_the_ranks_failure_without_a_gpu():
+    """`python bench.py --gpus 2` with no torch.distributed environment starts its own ranks (the parent touches no GPU and
+    does not exec).  In this container there is no HIP device: every rank must fail loudly ("no CPU fallback") and the
+    launcher must hand the failure on instead of printing a result line."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("covered on the GPU box by tests/test_gpu_round2.py::test_bench_gpus2_launches_two_ranks_itself")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert "needs a HIP device" in p.stderr
