@@ -435,13 +435,10 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     if (!active) return;
     const int base = (f * g.H + y) * g.Ws;
     const int hin = (run & 0xffff) - 1, cin = run >> 16;             // head and run count carried in from the left
-    Short8 h8;
-    {
-        int h = hin;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { if ((hm >> k) & 1) h = x0 + k; h8.v[k] = (int16_t)h; }
-    }
-    *(Short8*)(headmap + base + x0) = h8;
+    // head record of the chunk, one dword instead of eight head columns: (head carried in from the left + 1) | starts << 16.
+    // A pixel that is a disparity and not a run start belongs to the run of the nearest start to its left (in the chunk,
+    // else the carried one); k_spk_merge_strip<RS, true> rebuilds the few heads it needs from that.
+    ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + tid] = (uint32_t)(hin + 1) | (hm << 16);
     while (lm) {                                                      // one trip per run that ends in this chunk
         const int k = __builtin_ctz(lm);
         lm &= lm - 1;
@@ -456,7 +453,8 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     if (x0 + 8 >= W) rowcnt[f * g.H + y] = cin + __builtin_popcount(hm);
 }
 
-void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
+// Returns true if the head map was written as per-chunk records (k_lrcheck_vec) rather than one int16 per pixel.
+bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
                     hipStream_t stream, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                     int16_t* headmap, int spkDiff)
 {
@@ -477,6 +475,7 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
         const size_t lds = (size_t)Wp * 8 + 16;
         if (label) hipLaunchKernelGGL(k_lrcheck_vec<true>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
         else       hipLaunchKernelGGL(k_lrcheck_vec<false>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        return label != nullptr;
     } else if (label) {
         const int rr = lr_rows();
         if (k32) { if (rr == 4) RTDM_LR(true, uint16_t, uint32_t, 4); else if (rr == 2) RTDM_LR(true, uint16_t, uint32_t, 2); else RTDM_LR(true, uint16_t, uint32_t, 1); }
@@ -488,6 +487,7 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
         else RTDM_LR(false, int32_t, unsigned long long, 1);
     }
 #undef RTDM_LR
+    return false;
 }
 
 int lrcheck_rows_per_block() { return lr_rows(); }
@@ -594,7 +594,10 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
 // size / maxSize: a contact between two runs that are EACH longer than maxSize needs no union -- both components are
 // "large" whatever else they touch, and only "size <= maxSize" is ever asked (exact; it removes most unions: disparity
 // maps are made of long runs).  size[] still holds the run lengths here (k_spk_count runs afterwards).
-template <int RS>
+// COMPACT: the heads come as one record per 8-column chunk and row (k_lrcheck_vec: carried head + 1 | run starts << 16)
+// instead of one int16 per pixel: a quarter of the head bytes, and "same two runs as the pixel to the left" becomes bit
+// arithmetic (neither pixel of the pair starts a run).
+template <int RS, bool COMPACT>
 __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int Ws, int H,
                                                          int y_lo, int npairs, int newVal, int maxDiff, const int32_t* size, int maxSize)
 {
@@ -621,6 +624,8 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     Short8 a8, b8, ha8, hb8;
     if (inb) a8 = *(const Short8*)d;
     bool ha_loaded = false;
+    const uint32_t* hc = (const uint32_t*)headmap + (size_t)(f * H + y) * (Ws >> 3) + (x0 >> 3);   // COMPACT: this chunk's records
+    uint32_t ca = (COMPACT && inb) ? hc[0] : 0u;
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         unsigned cm = 0;
@@ -630,6 +635,27 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
             for (int k = 0; k < 8; ++k) cm |= (unsigned)conn(a8.v[k], b8.v[k], newVal, maxDiff) << k;
             cm &= colmask;
         }
+        if constexpr (COMPACT) {
+            const uint32_t cb = r < nr ? hc[(size_t)(r + 1) * (Ws >> 3)] : 0u;
+            // contact bit of the pixel left of the chunk: lane-1's bit 7, or (first lane of a wave) from memory
+            unsigned leftc = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(cm >> 7), 0x138, 0xf, 0xf, false);   // wave_shr:1
+            if ((threadIdx.x & 63) == 0) leftc = (cm && x0 > 0) ? (unsigned)conn(d[-1], d[disp.pitch_e - 1], newVal, maxDiff) : 0u;
+            if (x0 == 0) leftc = 0;                             // (lane-1 belongs to another strip there)
+            const unsigned startA = (ca >> 16) & 0xffu, startB = (cb >> 16) & 0xffu;
+            // a contact repeats the union of the contact to its left iff neither pixel of the pair starts a run
+            unsigned cand = cm & ~(((cm << 1) | (leftc & 1u)) & ~startA & ~startB);
+            while (cand) {
+                const int k = __builtin_ctz(cand);
+                cand &= cand - 1;
+                const unsigned ma = startA & ((2u << k) - 1u), mb = startB & ((2u << k) - 1u);
+                const int ha = ma ? x0 + (31 - __builtin_clz(ma)) : (int)(ca & 0xffffu) - 1;
+                const int hb = mb ? x0 + (31 - __builtin_clz(mb)) : (int)(cb & 0xffffu) - 1;
+                const int slot = atomicAdd(&qn, 1);
+                if (slot < QCAP) queue[slot] = make_int2(base + ha, base + Ws + hb);
+                else uf_union(label, base + ha, base + Ws + hb);
+            }
+            ca = cb;
+        } else {
         hb8.v[7] = 0;
         if (cm) {
             if (!ha_loaded) ha8 = *(const Short8*)h;
@@ -660,7 +686,9 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
                 pc = c; ph0 = ha; ph1 = hb;
             }
         }
-        a8 = b8; ha8 = hb8; ha_loaded = cm != 0;
+        ha8 = hb8; ha_loaded = cm != 0;
+        }
+        a8 = b8;
         d += disp.pitch_e; h += Ws; base += Ws;
     }
     __syncthreads();
@@ -714,7 +742,7 @@ __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t*
 // initialised by k_lrcheck<true> (rowcnt was zeroed before it) and no other row holds a valid pixel.
 void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
                     int W, int Ws, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
-                    int y_lo, int y_hi, hipStream_t stream)
+                    int y_lo, int y_hi, hipStream_t stream, bool compact_heads)
 {
     dim3 block(256);
     if (!init_done) {
@@ -735,11 +763,15 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         dim3 grid((nxb * npairs + 255) / 256, n);
         static int rs = -1;
         if (rs < 0) { const char* e = getenv("RTDM_MERGE_STRIP"); rs = e ? atoi(e) : 4; }
+        if (compact_heads) {                       // written by k_lrcheck_vec, whose alignment conditions imply `vec` and step == 1
+            dim3 sgrid((nxb * ((npairs + 3) / 4) + 255) / 256, n);
+            hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
+        } else
         if (vec && step == 1 && rs > 1) {
             const int RSV = rs >= 8 ? 8 : 4;
             dim3 sgrid((nxb * ((npairs + RSV - 1) / RSV) + 255) / 256, n);
-            if (RSV == 8) hipLaunchKernelGGL(k_spk_merge_strip<8>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
-            else          hipLaunchKernelGGL(k_spk_merge_strip<4>, sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
+            if (RSV == 8) hipLaunchKernelGGL((k_spk_merge_strip<8, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
+            else          hipLaunchKernelGGL((k_spk_merge_strip<4, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
         } else
         if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);

@@ -440,16 +440,17 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
     const bool speckle = p.speckleRange >= 0 && p.speckleWindowSize > 0;
     const bool lr = p.disp12MaxDiff >= 0;
     if (speckle) HIPC(hipMemsetAsync(ln.dRowCnt, 0, (size_t)n * H * sizeof(int32_t), s));
+    bool compact_heads = false;
     if (lr) {
         stage_begin(bm, RTDM_STAGE_LRCHECK, n, s, &ev);
-        if (speckle) launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, p.speckleRange);
+        if (speckle) compact_heads = launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, p.speckleRange);
         else         launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s);
         stage_end(bm, s, &ev);
     }
     if (speckle) {
         stage_begin(bm, RTDM_STAGE_SPECKLE, n, s, &ev);
         launch_speckle(disp, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, W, g.Ws, H, n, g.filtered, p.speckleWindowSize,
-                       p.speckleRange, lr, lr ? lrcheck_rows_per_block() : 1, g.vy0, g.vy1, s);
+                       p.speckleRange, lr, lr ? lrcheck_rows_per_block() : 1, g.vy0, g.vy1, s, compact_heads);
         stage_end(bm, s, &ev);
     }
     HIPC(hipGetLastError());

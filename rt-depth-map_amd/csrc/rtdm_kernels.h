@@ -70,7 +70,8 @@ void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const
 
 // K3: row-local left-right consistency check (+ column masking to the valid rectangle).  With
 // label != nullptr the speckle filter's per-row init runs on the checked row in the same pass.
-void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
+// Returns true if the speckle head map was written as per-chunk records (pass that on to launch_speckle).
+bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
                     hipStream_t stream, int32_t* label = nullptr, int32_t* size = nullptr,
                     uint32_t* runs = nullptr, int32_t* rowcnt = nullptr, int16_t* headmap = nullptr, int spkDiff = 0);
 
@@ -81,7 +82,7 @@ void launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
 // (lrcheck_rows_per_block() for launch_lrcheck).
 void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt, int16_t* headmap,
                     int W, int Ws, int H, int n, int newVal, int maxSize, int maxDiff, bool init_done, int premerged_rows,
-                    int y_lo, int y_hi, hipStream_t stream);
+                    int y_lo, int y_hi, hipStream_t stream, bool compact_heads = false);
 // Ws = row stride of label/size/runs/headmap (>= W)
 // n frames of W x H int16: src -> dst (any pitches)
 void launch_copy16(Plane16W src, Plane16W dst, int W, int H, int n, hipStream_t stream);
