@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
-B="--steps 2 --warmup 2 --batch 256 --no-cpu-baseline"    # the bench's own batch; warm-up 2: the second call measures the strip count
+B="--steps 2 --warmup 2 --batch 1024 --no-cpu-baseline"    # the bench's own batch; warm-up 2: the second call measures the strip count
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- $R/tools/ubench_fetch > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $R/tools/ubench_fetch > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_fetch -- python $R/bench.py $B > /dev/null 2>&1
@@ -36,7 +36,7 @@ for d in ("cal_fetch", "cal_write", "bench_fetch", "bench_write", "bench_sq"):
                 key = re.sub(r"^void ", "", k).replace("rtdm::", "").replace(", ", ",")
                 data.setdefault(key, {})[c] = sum(v) / len(v)
 open("$OUT/summary.txt", "w").write("\n".join(lines) + "\n")
-PAIRS = 256
+PAIRS = 1024
 out = {"kernel_source_sha": _bench.kernel_source_sha(), "source": "tools/pmc_traffic.sh (rocprofv3 --pmc, separate passes)", "pairs_per_launch": PAIRS, "workload": "1280x720 d=64 9x9",
        "fetch_correction": 2.0, "unit": "KB (FETCH_SIZE reads 1/2 on gfx950, calibrated with tools/ubench_fetch; WRITE_SIZE exact)",
        "sq_unit": "quad-cycles summed over all waves / SIMDs; GRBM_GUI_ACTIVE summed over the 8 XCDs", "kernels": {}}
