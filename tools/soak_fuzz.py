@@ -32,5 +32,37 @@ for seed in range(first, first + count):
     if not np.array_equal(got, want):
         bad += 1
         print("MISMATCH seed", seed, W, H, kw, roi1, roi2, int((got != want).sum()))
-print("checked", count, "mismatches", bad, variants)
+print("checked", count, "mismatches", bad, variants, flush=True)
+
+# ---- second part: the ring kernel's own table on taller frames and device batches (strip boundaries, the 16-bit cap of
+# ---- a strip, the side-stream border kernel, the autotuned strip count on the second and third call)
+RING = [(64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9)]
+st = torch.cuda.current_stream().cuda_stream
+for seed in range(first, first + max(1, count // 10)):
+    rng = np.random.default_rng(seed + 777)
+    D, w = RING[int(rng.integers(0, len(RING)))]
+    W, H = int(rng.integers(D + w + 40, D + w + 700)), int(rng.integers(w + 40, 420))
+    n = int(rng.choice([1, 2, 5, 16, 20]))
+    cap = int(rng.choice([31, 31, 63 if 126 * w * w <= 32766 else 31, 7]))
+    kw = dict(numDisparities=D, blockSize=w, preFilterCap=cap, minDisparity=int(rng.choice([0, 0, -6, 4])),
+              uniquenessRatio=int(rng.choice([10, 0, 25])), textureThreshold=int(rng.choice([10, 0, 100])),
+              speckleWindowSize=int(rng.choice([100, 0, 30])), speckleRange=int(rng.choice([32, 2])), disp12MaxDiff=int(rng.choice([1, -1, 0])))
+    Ls, Rs = pkg.synth.make_stream(seed % 1000, n, W, H, D)
+    dL, dR = torch.from_numpy(Ls).cuda(), torch.from_numpy(Rs).cuda()
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n,
+                       **{k: v for k, v in kw.items() if k not in ("numDisparities", "blockSize")})
+    for rep in range(3):
+        dD.fill_(12345)
+        m.compute_device(dL, dR, dD, st)
+        torch.cuda.synchronize()
+    variants[m.search_variant] = variants.get(m.search_variant, 0) + 1
+    got = dD.cpu().numpy()
+    m.close()
+    for i in sorted({0, n // 2, n - 1}):
+        want = orc.bm_compute(Ls[i], Rs[i], nthreads=8, **kw)
+        if not np.array_equal(got[i], want):
+            bad += 1
+            print("MISMATCH ring seed", seed, W, H, n, i, kw, int((got[i] != want).sum()))
+print("ring part done, total mismatches", bad, variants)
 sys.exit(1 if bad else 0)
