@@ -266,8 +266,14 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
     commit(Set0{}, 0); commit(Set1{}, 1);           // rows 0 and 1 -> slots 0 and 1
     issue(Set0{});                                  // row 2: committed at the end of step 0
 
-    int16_t* db = disp.base + (size_t)f * disp.frame_e;
+    // Output addresses: a wave-uniform frame base plus a 32-bit byte offset per lane that advances two rows per pair
+    // (the host checks that a frame's planes stay below 4 GB) -- no 64-bit multiply per store.
+    char* const db = (char*)(disp.base + (size_t)f * disp.frame_e);
+    char* const cb = (char*)(cost + (size_t)f * g.H * g.Ws);
     const int col = g.lofs + x;
+    uint32_t dofs = (uint32_t)(((size_t)(ys0 + h) * disp.pitch_e + col) * 2);     // row of the first pair with output
+    uint32_t cofs = (uint32_t)(((size_t)(ys0 + h) * g.Ws + col) * 2);
+    const uint32_t dstep = (uint32_t)(disp.pitch_e * 4), cstep = (uint32_t)(g.Ws * 4);
     const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
 
     uint32_t S0[NRL], S1[NRL];
@@ -354,8 +360,10 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
             // Selection is skipped for a wave none of whose pixels can produce a disparity here (untextured, outside the
             // tile, masked): exact, such a pixel is FILTERED and writes no cost whatever its SADs are.
             const bool dead = !active || !row_ok || masked_col || tsum < g.tex;
+            const uint32_t dof = dofs, cof = cofs;
+            dofs += dstep; cofs += cstep;
             if (__builtin_amdgcn_ballot_w64(!dead) == 0) {
-                if (active && row_ok) db[(size_t)y * disp.pitch_e + col] = (int16_t)g.filtered;
+                if (active && row_ok) *(int16_t*)(db + dof) = (int16_t)g.filtered;
             } else {
                 int m1; bool fail;
 #if RING_ABL == 1 || RING_ABL == 6
@@ -373,8 +381,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
 #else
                 if (active && row_ok) {
 #endif
-                    if (!fail && g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)m1;
-                    db[(size_t)y * disp.pitch_e + col] = (int16_t)(masked_col ? g.filtered : out);
+                    if (!fail && g.want_cost) *(uint16_t*)(cb + cof) = (uint16_t)m1;
+                    *(int16_t*)(db + dof) = (int16_t)(masked_col ? g.filtered : out);
                 }
             }
             RING_STAMP(6);                                          // selection + stores
@@ -460,6 +468,7 @@ bool ring_search_supported(const BMGeom& g)
     if (2L * g.cap * g.w * g.w > 32766) return false;       // packed u16 sums + the T+1 <= 32767 argument of the selection
     if (ring_rows_cap(g) < 2) return false;
     if (!ring_range(g, nullptr, nullptr)) return false;
+    if ((size_t)g.H * (size_t)g.Ws * 2 >= ((size_t)1 << 32)) return false;   // 32-bit byte offsets inside a frame (pitch <= Ws)
 #define X(DD, WW) if (g.D == DD && g.w == WW) return true;
     RTDM_RING_TABLE(X)
 #undef X

@@ -32,11 +32,11 @@ __device__ __forceinline__ int sel_div_trunc(int num, int den)   // den > 0, |nu
 {
     const unsigned an = (unsigned)(num < 0 ? -num : num);
     unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
-    int rem = (int)an - (int)(q * (unsigned)den);
-    if (rem < 0) { --q; rem += den; }
-    if (rem < 0) { --q; rem += den; }
-    if (rem >= den) { ++q; rem -= den; }
-    if (rem >= den) { ++q; }
+    // an, den < 2^24 are exact in float; rcp and the product are each within an ulp, so for quotients below 2^15 (here
+    // |num / den| <= 128) the estimate is off by less than one: one correction each way is enough
+    const int rem = (int)an - (int)(q * (unsigned)den);
+    if (rem < 0) --q;
+    else if (rem >= den) ++q;
     return num < 0 ? -(int)q : (int)q;
 }
 
