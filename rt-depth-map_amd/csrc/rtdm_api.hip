@@ -43,6 +43,8 @@ struct Lane {
     hipEvent_t done;
     hipStream_t side;              // the border-column search runs here, next to the tile search (RTDM_BORDER_ASYNC)
     hipEvent_t fork, join;
+    hipStream_t back;              // two-lane mode: left-right check and speckle filter of the lane's piece run here
+    hipEvent_t mid;                // ... after this event (the piece's search is complete)
     uint8_t *dLp, *dRp;
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
@@ -186,7 +188,12 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     }
     {   // lanes: slices of the workspace (lane 1 starts laneB frames in)
         const char* env = getenv("RTDM_LANES");
-        bm->nlanes = (max_batch >= 2 && env && atoi(env) == 2) ? 2 : 1;   // opt-in: measured +1 % only, and it blurs per-kernel timings
+        // opt-in.  Measured in round 2 with the ring kernel (profiles/r02_two_lane_pipeline_ab.txt): the row kernels of piece k
+        // under the search of piece k+1 give 51.8 k pairs/s with 2 pieces and 51.2 k with 4 against 52.1 k on one lane -- a
+        // search wave loses as many issue slots to a co-resident row-kernel wave as the overlap hides; with the front stream at
+        // high and the back streams at low priority the row kernels starve (left-right check 1.7 -> 4.5 ms) and the search
+        // still slows by 8 %: 47.7 k.
+        bm->nlanes = (max_batch >= 2 && env && atoi(env) == 2) ? 2 : 1;
         bm->laneB = bm->nlanes == 2 ? (max_batch + 1) / 2 : max_batch;
         HIPC(hipEventCreateWithFlags(&bm->evIn, hipEventDisableTiming));
         for (int k = 0; k < bm->nlanes; ++k) {
@@ -198,6 +205,8 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
             HIPC(hipStreamCreateWithFlags(&ln.side, hipStreamNonBlocking));
             HIPC(hipEventCreateWithFlags(&ln.fork, hipEventDisableTiming));
             HIPC(hipEventCreateWithFlags(&ln.join, hipEventDisableTiming));
+            HIPC(hipStreamCreateWithFlags(&ln.back, hipStreamNonBlocking));
+            HIPC(hipEventCreateWithFlags(&ln.mid, hipEventDisableTiming));
             ln.dLp = bm->dLp + fo * bm->ppitch * max_height; ln.dRp = bm->dRp + fo * bm->ppitch * max_height;
             ln.dCost = bm->dCost + po; ln.dLabel = bm->dLabel + po; ln.dSize = bm->dSize + po;
             ln.dRuns = bm->dRuns + po; ln.dHead = bm->dHead + po; ln.dOut = bm->dOut + po; ln.dRowCnt = bm->dRowCnt + fo * max_height;
@@ -218,6 +227,8 @@ void rtdm_bm_destroy(rtdm_bm* bm)
         if (bm->lane[k].side) { (void)hipStreamSynchronize(bm->lane[k].side); (void)hipStreamDestroy(bm->lane[k].side); }
         if (bm->lane[k].fork) (void)hipEventDestroy(bm->lane[k].fork);
         if (bm->lane[k].join) (void)hipEventDestroy(bm->lane[k].join);
+        if (bm->lane[k].back) { (void)hipStreamSynchronize(bm->lane[k].back); (void)hipStreamDestroy(bm->lane[k].back); }
+        if (bm->lane[k].mid) (void)hipEventDestroy(bm->lane[k].mid);
     }
     if (bm->evIn) (void)hipEventDestroy(bm->evIn);
     for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
@@ -295,7 +306,9 @@ static void stage_end(rtdm_bm* bm, hipStream_t s, StageEvent* ev)
     bm->pending.push_back(*ev);
 }
 
-static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s);
+static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s,
+                       BMGeom* gout, bool* anyout);
+static int chunk_back(rtdm_bm* bm, const Lane& ln, int n, int W, int H, Plane16W disp, const BMGeom& g, hipStream_t s);
 
 // Row strips per frame for the fast search of a batch, chosen by measurement and remembered in the handle: the model
 // (fast_strips_model) is right on average, but neighbouring strip counts differ by up to 5 % through scheduling effects it
@@ -364,25 +377,39 @@ static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plan
 // W rounded up to 8 elements whose padding is ours to write.  A caller's plane qualifies only if W % 8 == 0 and it
 // is aligned; anything else (the reference's own crops are 233, 534 and 934 columns wide) runs on the lane's
 // internal plane and is copied out at the end.
-static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W out, hipStream_t s)
+// `back` (two-lane mode): the stream the chunk's row kernels run on, behind the event ln.mid recorded after the search;
+// nullptr = everything on `s`.
+static int run_chunk(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W out, hipStream_t s,
+                     hipStream_t back = nullptr)
 {
     const size_t Ws = (size_t)((W + 7) & ~7);
     const bool internal = out.base == ln.dOut && out.pitch_e == Ws;
     const bool direct = internal || ((W & 7) == 0 && (((size_t)out.base | (out.pitch_e * 2) | (out.frame_e * 2)) & 15) == 0);
-    if (direct) return run_chunk_on(bm, ln, n, L, R, W, H, out, s);
-    Plane16W tmp{ln.dOut, Ws, Ws * (size_t)H};
-    const int rc = run_chunk_on(bm, ln, n, L, R, W, H, tmp, s);
+    const Plane16W disp = direct ? out : Plane16W{ln.dOut, Ws, Ws * (size_t)H};
+    BMGeom g;
+    bool any = false;
+    int rc = chunk_front(bm, ln, n, L, R, W, H, disp, s, &g, &any);
     if (rc) return rc;
-    launch_copy16(tmp, out, W, H, n, s);
+    hipStream_t b = s;
+    if (back) {
+        HIPC(hipEventRecord(ln.mid, s));
+        HIPC(hipStreamWaitEvent(back, ln.mid, 0));
+        b = back;
+    }
+    if (any) { rc = chunk_back(bm, ln, n, W, H, disp, g, b); if (rc) return rc; }
+    if (!direct) launch_copy16(disp, out, W, H, n, b);
     HIPC(hipGetLastError());
     return RTDM_OK;
 }
 
-static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s)
+// Fill + prefilter + SAD search of a chunk (VALU bound); *any = false: the whole frame is FILTERED, nothing follows.
+static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, int W, int H, Plane16W disp, hipStream_t s,
+                       BMGeom* gout, bool* anyout)
 {
     const rtdm_bm_params& p = bm->p;
-    BMGeom g;
+    BMGeom& g = *gout;
     const bool any = make_geom(bm, W, H, &g);
+    *anyout = any;
     if (!any) { launch_fill16(disp, 0, W, 0, H, n, g.filtered, s); return RTDM_OK; }
     // the search kernels write columns [cx0, cx1) of the valid rows; everything else is FILTERED
     launch_fill16(disp, 0, W, 0, g.vy0, n, g.filtered, s);
@@ -437,6 +464,15 @@ static int run_chunk_on(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, 
         }
         stage_end(bm, s, &ev);
     }
+    HIPC(hipGetLastError());
+    return RTDM_OK;
+}
+
+// Left-right check + speckle filter of a chunk, in place on `disp` (latency bound).
+static int chunk_back(rtdm_bm* bm, const Lane& ln, int n, int W, int H, Plane16W disp, const BMGeom& g, hipStream_t s)
+{
+    const rtdm_bm_params& p = bm->p;
+    StageEvent ev;
     const bool speckle = p.speckleRange >= 0 && p.speckleWindowSize > 0;
     const bool lr = p.disp12MaxDiff >= 0;
     if (speckle) HIPC(hipMemsetAsync(ln.dRowCnt, 0, (size_t)n * H * sizeof(int32_t), s));
@@ -488,27 +524,33 @@ int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint
         }
         return RTDM_OK;
     }
-    // two lanes: the caller's stream fans out to the lane streams and joins them again
+    // Two lanes: the batch is cut into pieces whose searches run back to back on ONE front stream (two searches side by
+    // side would only share the VALUs), while the row kernels of piece k (latency bound, <= 40 VGPRs: their waves fit beside
+    // the two 232-VGPR search waves of a SIMD) run on the lane's back stream under the search of piece k+1.  The pieces
+    // alternate between the two workspace slices; a slice is reused once its previous piece's row kernels are done.
+    // RTDM_PIECES = pieces per call.
+    hipStream_t front = bm->lane[0].stream;
     HIPC(hipEventRecord(bm->evIn, s));
-    for (int k = 0; k < 2; ++k) HIPC(hipStreamWaitEvent(bm->lane[k].stream, bm->evIn, 0));
-    // pieces alternate between the lanes; more than two make the lanes drift out of phase, so that one lane's row kernels
-    // (memory / latency bound) run under the other lane's search (VALU bound).  RTDM_PIECES = pieces per call.
+    HIPC(hipStreamWaitEvent(front, bm->evIn, 0));
     static int npieces = 0;
-    if (!npieces) { const char* e = getenv("RTDM_PIECES"); npieces = e ? atoi(e) : 2; if (npieces < 2) npieces = 2; }
+    if (!npieces) { const char* e = getenv("RTDM_PIECES"); npieces = e ? atoi(e) : 4; if (npieces < 2) npieces = 2; }
     const int piece = std::max(1, std::min(bm->laneB, (n + npieces - 1) / npieces));
+    bool used[2] = {false, false};
     int k = 0;
     for (int i0 = 0; i0 < n; i0 += piece, k ^= 1) {
         const int m = std::min(piece, n - i0);
+        Lane& ln = bm->lane[k];
+        if (used[k]) HIPC(hipStreamWaitEvent(front, ln.done, 0));
         Plane8 L{d_left + (size_t)i0 * frame_stride, pitch, frame_stride};
         Plane8 R{d_right + (size_t)i0 * frame_stride, pitch, frame_stride};
         Plane16W O{d_disp + (size_t)i0 * (disp_frame_stride / 2), disp_pitch / 2, disp_frame_stride / 2};
-        rc = run_chunk(bm, bm->lane[k], m, L, R, width, height, O, bm->lane[k].stream);
+        rc = run_chunk(bm, ln, m, L, R, width, height, O, front, ln.back);
         if (rc) return rc;
+        HIPC(hipEventRecord(ln.done, ln.back));
+        used[k] = true;
     }
-    for (int q = 0; q < 2; ++q) {
-        HIPC(hipEventRecord(bm->lane[q].done, bm->lane[q].stream));
-        HIPC(hipStreamWaitEvent(s, bm->lane[q].done, 0));
-    }
+    for (int q = 0; q < 2; ++q)
+        if (used[q]) HIPC(hipStreamWaitEvent(s, bm->lane[q].done, 0));
     return RTDM_OK;
 }
 
