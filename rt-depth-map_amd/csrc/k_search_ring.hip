@@ -43,6 +43,11 @@
 #ifndef RING_LDS_SELECT   // 1: select_disparity_lds (fetches through LDS), 0: select_disparity (v_cndmask tree)
 #define RING_LDS_SELECT 1
 #endif
+#ifndef RING_SPLIT_SELECT // 1: select_split_lds (the halves of a lane pair are not transposed: three swaps instead of D/4).
+#define RING_SPLIT_SELECT 0 // Same results; measured within +-2 % of the transposing form on all 36 cases and 0.8 % slower on the
+                            // headline (profiles/r02_ring_split_select_ab.txt): the three swaps sit on the selection's
+                            // dependency chain, the D/4 of the transposing form pipeline.  tools/ring_split_ab.sh
+#endif
 
 #ifdef RING_STAMPS        // diagnostic build only (tools/ring_stamps.sh): where a row pair spends its cycles
 __device__ unsigned long long ring_stamps[8];
@@ -203,6 +208,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
     uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][64]
 #if RING_LDS_SELECT
     uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;   // this lane's selection record
+    uint32_t* scr_a = stg + C::STG + p * SelRecord<D>::DWORDS + h * NRL;   // where this lane's half of the lower lane's row goes
+    uint32_t* scr_b = scr_a + 32 * SelRecord<D>::DWORDS;                   // ... and of the upper lane's row
 #endif
 
     // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
@@ -343,6 +350,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
             if (t < WS - 1) return true;                            // the window is still filling (WS - 1 is even)
             // lanes l and l+32 hold the two halves of a pixel for rows t (S0) and t+1 (S1): after the swap the lower lane
             // has both halves of row t and the upper lane both halves of row t+1
+#if !(RING_SPLIT_SELECT && RING_LDS_SELECT && RING_ABL == 0)
             uint32_t rr[D / 2];
 #pragma unroll
             for (int i = 0; i < NRL; ++i) {
@@ -353,6 +361,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
                 rr[i] = sw[0]; rr[NRL + i] = sw[1];
 #endif
             }
+#endif
             RING_STAMP(5);                                          // swaps
             const int tsum = h ? ts1 : ts0;
             const int y = ys0 + (t - (WS - 1)) + h;
@@ -371,6 +380,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
 #pragma unroll
                 for (int i = 0; i < D / 2; ++i) xo ^= rr[i];
                 const int out = (int)xo; m1 = (int)(xo >> 3); fail = (xo & 1) != 0;
+#elif RING_LDS_SELECT && RING_SPLIT_SELECT && RING_ABL == 0
+                const int out = select_split_lds<D>(S0, S1, h, tsum, g, scr, scr_a, scr_b, &m1, &fail);
 #elif RING_LDS_SELECT
                 const int out = select_disparity_lds<D>(rr, tsum, g, scr, &m1, &fail);
 #else

@@ -237,4 +237,104 @@ __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2],
     return out;
 }
 
+// The LDS selection for k_search_ring's lane pairs, without transposing the SADs first.  Lanes l and l+32 (h = 0 / 1) each
+// hold one HALF of the D values -- indices [h D/2, (h+1) D/2) -- of TWO pixel rows: sa belongs to the row owned by lane l,
+// sb to the row owned by lane l+32.  Each lane writes its two halves into the owners' records, runs level one (group
+// minima and keys) and the uniqueness sums on what it holds -- the same work as for one whole row -- and only three
+// values cross between the halves (v_permlane32_swap): the partial key minima, the owners' thresholds T+1 and the
+// partial sums.  Everything after that is the owner's: winning group back from its record, argmin inside it, sad[a-1],
+// sad[a+1], the tests, the sub-pixel step.  Results are those of select_disparity_lds on the transposed values.
+//   rec_own: this lane's record; wr_a / wr_b: where this lane's halves go (record of lane l / l+32, offset h D/4 dwords).
+template <int D>
+__device__ __forceinline__ int select_split_lds(const uint32_t (&sa)[D / 4], const uint32_t (&sb)[D / 4], int h, int tsum,
+                                                const BMGeom& g, uint32_t* rec_own, uint32_t* wr_a, uint32_t* wr_b,
+                                                int* minsad, bool* rejected)
+{
+    constexpr int NRL = D / 4, NGH = NRL / 4;          // registers and groups of eight per half
+    static_assert(D == 16 || D == 32 || D == 48 || D == 64, "record stride checked for these sizes only");
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int i = 0; i < NRL; i += 4) *(u4*)(wr_a + i) = u4{sa[i], sa[i + 1], sa[i + 2], sa[i + 3]};
+#pragma unroll
+    for (int i = 0; i < NRL; i += 4) *(u4*)(wr_b + i) = u4{sb[i], sb[i + 1], sb[i + 2], sb[i + 3]};
+    // level one: key = min << 8 | group (group counted inside the half; the half's offset is added to the minimum)
+    uint32_t gma[NGH], gmb[NGH];
+    uint32_t ka = 0xffffffffu, kb = 0xffffffffu;
+#pragma unroll
+    for (int gq = 0; gq < NGH; ++gq) {
+        const uint32_t ga = sel_pk_min(sel_pk_min(sa[4 * gq], sa[4 * gq + 1]), sel_pk_min(sa[4 * gq + 2], sa[4 * gq + 3]));
+        const uint32_t gb = sel_pk_min(sel_pk_min(sb[4 * gq], sb[4 * gq + 1]), sel_pk_min(sb[4 * gq + 2], sb[4 * gq + 3]));
+        gma[gq] = ga; gmb[gq] = gb;
+        ka = min(ka, (min(ga & 0xffffu, ga >> 16) << 8) | (uint32_t)gq);
+        kb = min(kb, (min(gb & 0xffffu, gb >> 16) << 8) | (uint32_t)gq);
+    }
+    const uint32_t hofs = (uint32_t)(h * NGH);
+    ka += hofs; kb += hofs;
+    // lower lane: {own ka, partner's ka}; upper lane: {partner's kb, own kb}  =>  the owner's minimum over both halves
+    const auto swk = __builtin_amdgcn_permlane32_swap(ka, kb, false, false);
+    const uint32_t kmin = min(swk[0], swk[1]);
+    const int m1 = (int)(kmin >> 8);
+    const int gs = (int)(kmin & 0xffu);
+    const u4 grp = *(const u4*)(rec_own + 4 * gs);               // the four registers of the winning group
+    uint32_t z = 0, T1 = 0;
+    if (g.uniq > 0) {
+        uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
+        T = min(T, 32766u);
+        T1 = T + 1u;
+        const auto swt = __builtin_amdgcn_permlane32_swap(T1, T1, false, false);   // every lane: {T+1 of row a, T+1 of row b}
+        const auto usum = [&](const uint32_t (&sv)[NRL], const uint32_t (&gm)[NGH], uint32_t t1) -> uint32_t {
+            const uint32_t t1pk = t1 * 0x00010001u;
+            uint32_t zz[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < NRL; i += 4) {
+                // a group none of whose eight values reaches the threshold in any lane adds nothing (exact)
+                if (__builtin_amdgcn_ballot_w64(sel_pk_sub_sat(t1pk, gm[i >> 2]) != 0u) == 0) continue;
+                uint32_t t0 = sel_pk_sub_sat(t1pk, sv[i]), t1v = sel_pk_sub_sat(t1pk, sv[i + 1]);
+                uint32_t t2 = sel_pk_sub_sat(t1pk, sv[i + 2]), t3 = sel_pk_sub_sat(t1pk, sv[i + 3]);
+                asm volatile("" : "+v"(t0), "+v"(t1v), "+v"(t2), "+v"(t3));
+                zz[0] = sel_pk_add_sat(zz[0], t0); zz[1] = sel_pk_add_sat(zz[1], t1v);
+                zz[2] = sel_pk_add_sat(zz[2], t2); zz[3] = sel_pk_add_sat(zz[3], t3);
+            }
+            const uint32_t zp = sel_pk_add_sat(sel_pk_add_sat(zz[0], zz[1]), sel_pk_add_sat(zz[2], zz[3]));
+            // a 16-bit half saturates at 65535, more than the (at most two) terms of {a-1, a, a+1} it can hold add up to:
+            // the total stays >= the expected total, with equality only if nothing saturated and nothing else contributed
+            return (zp & 0xffffu) + (zp >> 16);
+        };
+        const uint32_t za = usum(sa, gma, swt[0]);
+        const uint32_t zb = usum(sb, gmb, swt[1]);
+        const auto swz = __builtin_amdgcn_permlane32_swap(za, zb, false, false);    // the owner gets both halves of its row's sum
+        z = swz[0] + swz[1];
+    }
+    uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
+        const uint32_t klo = __builtin_amdgcn_perm(grp[q], ec, 0x0C050400u);
+        const uint32_t khi = __builtin_amdgcn_perm(grp[q], ec, 0x0C070601u);
+        k3[q & 1] = min(min(k3[q & 1], klo), khi);
+    }
+    const int a = 8 * gs + (int)(min(k3[0], k3[1]) & 0xffu);
+    const bool has_n = a > 0, has_p = a + 1 < D;
+    const unsigned short* sv = (const unsigned short*)rec_own;
+    const int n_real = sv[has_n ? a - 1 : a];
+    const int p_real = sv[has_p ? a + 1 : a];
+    bool fail = tsum < g.tex;
+    if (g.uniq > 0) {
+        const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
+        const uint32_t want = term(m1) + (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
+        fail |= z != want;
+    }
+    int out = g.filtered;
+    if (!fail) {
+        const int pp = has_p ? p_real : n_real;
+        const int nn = has_n ? n_real : p_real;
+        const int den = pp + nn - 2 * m1 + abs(pp - nn);
+        const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
+        out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
+    }
+    *minsad = m1;
+    *rejected = fail;
+    return out;
+}
+
 }  // namespace rtdm
