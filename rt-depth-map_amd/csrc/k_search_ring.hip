@@ -208,8 +208,10 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
     uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][64]
 #if RING_LDS_SELECT
     uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;   // this lane's selection record
+#if RING_SPLIT_SELECT
     uint32_t* scr_a = stg + C::STG + p * SelRecord<D>::DWORDS + h * NRL;   // where this lane's half of the lower lane's row goes
     uint32_t* scr_b = scr_a + 32 * SelRecord<D>::DWORDS;                   // ... and of the upper lane's row
+#endif
 #endif
 
     // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
