@@ -72,16 +72,19 @@ struct RingGeom {
     unsigned nitems;     // workgroups over the whole batch
 };
 
-template <int D, int WS>
+// LPP = lanes per pixel: the D disparities of a pixel are split over LPP lanes of a wave (p + h * 64/LPP, h = 0..LPP-1), and
+// rows are processed in groups of LPP, one owner lane per row for the selection.
+template <int D, int WS, int LPP = 2>
 struct RingCfg {
     static constexpr int NP = (WS + 3) / 4;        // 4-byte pieces of a window row
     static constexpr int W1 = WS + 1;              // ring slots
-    static constexpr int DL = D / 2;               // disparities per lane
+    static constexpr int PPW = 64 / LPP;           // pixels (columns) per wave
+    static constexpr int DL = D / LPP;             // disparities per lane
     static constexpr int NGL = DL / 4;             // quad-SAD groups per lane
     static constexpr int NRL = DL / 2;             // packed u16x2 registers per lane and slot
     static constexpr int NW = NGL + NP - 1;        // distinct 8-byte right windows per lane and row
-    static constexpr int LWD = 32 + NP;            // dwords of the wave's copy of the left row
-    static constexpr int RWD = 32 + D / 4 + NP;    //                                 right row
+    static constexpr int LWD = PPW + NP;           // dwords of the wave's copy of the left row
+    static constexpr int RWD = PPW + D / 4 + NP;   //                                 right row
     static constexpr int ITEMS = (LWD + RWD + 63) / 64;
     static constexpr int SLOT = ITEMS * 64;        // padded: every lane stores every item, no exec masking
     static constexpr int NSLOT = 3;                // staged rows in flight per wave
@@ -89,22 +92,25 @@ struct RingCfg {
     static constexpr int WAVE_LDS = STG + 64 * SelRecord<D>::DWORDS;   // + the selection's per-lane records (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
-    static constexpr int WAVES = RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
-    static constexpr int TILE = 128;
+    static constexpr int WAVES = LPP == 4 ? 3 : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
+    static constexpr int TILE = 4 * PPW;           // four byte phases
+    // rows per trip of the unrolled row loop: whole rounds of the ring AND whole groups
+    static constexpr int TRIP = (W1 % LPP == 0) ? W1 : (2 * W1 % LPP == 0) ? 2 * W1 : 4 * W1;
+    static_assert(W1 % 2 == 0 && TRIP % LPP == 0 && TRIP % W1 == 0, "block sizes are odd");
 };
 
-template <int D, int WS>
-struct RingState { uint64_t P[RingCfg<D, WS>::W1][RingCfg<D, WS>::NGL]; };   // only ever indexed with constants: registers
+template <int D, int WS, int LPP = 2>
+struct RingState { uint64_t P[RingCfg<D, WS, LPP>::W1][RingCfg<D, WS, LPP>::NGL]; };   // only ever indexed with constants: registers
 
 // The registers a lane needs of one staged row: its NW right windows (8 bytes each) and its NP left pieces.
-template <int D, int WS>
-struct RowRegs { uint64_t win[RingCfg<D, WS>::NW]; uint32_t l[RingCfg<D, WS>::NP]; };
+template <int D, int WS, int LPP = 2>
+struct RowRegs { uint64_t win[RingCfg<D, WS, LPP>::NW]; uint32_t l[RingCfg<D, WS, LPP>::NP]; };
 
 // lp / rp: this lane's left pieces / right windows of the staged row in LDS.
-template <int D, int WS>
-__device__ __forceinline__ void ring_load_row(const uint32_t* __restrict__ lp, const uint32_t* __restrict__ rp, RowRegs<D, WS>& rw)
+template <int D, int WS, int LPP>
+__device__ __forceinline__ void ring_load_row(const uint32_t* __restrict__ lp, const uint32_t* __restrict__ rp, RowRegs<D, WS, LPP>& rw)
 {
-    using C = RingCfg<D, WS>;
+    using C = RingCfg<D, WS, LPP>;
     // 64-bit operands want even-aligned VGPR pairs: windows at odd dword offsets are loaded through a second pointer
     // whose index is laundered, so that they get their own ds_read2_b32 instead of v_mov rebuilds.
     // Issue order = order of first use (the LDS returns data in order): the left pieces, then the windows by index.
@@ -122,11 +128,11 @@ __device__ __forceinline__ void ring_load_row(const uint32_t* __restrict__ lp, c
 
 // One row step on ring slot K: P[K] = P[K-1] + H(row), S = P[K] - P[K+1] (the slot that holds P(t-w));
 // tnew += the row's texture term sum |L - cap|.
-template <int D, int WS, int K, int NRLc>
-__device__ __forceinline__ void ring_step(RingState<D, WS>& st, const RowRegs<D, WS>& rw, uint32_t lastmask, uint32_t capb,
+template <int D, int WS, int LPP, int K, int NRLc>
+__device__ __forceinline__ void ring_step(RingState<D, WS, LPP>& st, const RowRegs<D, WS, LPP>& rw, uint32_t lastmask, uint32_t capb,
                                           uint32_t& tnew, uint32_t (&S)[NRLc])
 {
-    using C = RingCfg<D, WS>;
+    using C = RingCfg<D, WS, LPP>;
     auto& P = st.P;
     constexpr int NP = C::NP, NGL = C::NGL, W1 = C::W1;
     constexpr int KP = (K + W1 - 1) % W1, KO = (K + 1) % W1;
@@ -171,17 +177,21 @@ __device__ __forceinline__ void pin(uint32_t (&v)[N])
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i]));
 }
 
-// compile-time loop over the row pairs of one trip round the ring; f(pair index constant) returns false to stop
+// compile-time loops: over the row groups of one trip of the row loop (f returns false to stop) and over a group's rows
 template <typename F, int... U>
-__device__ __forceinline__ void ring_for_pairs(std::integer_sequence<int, U...>, F&& f)
+__device__ __forceinline__ void ring_for_groups(std::integer_sequence<int, U...>, F&& f)
 { (void)(f(std::integral_constant<int, U>{}) && ...); }
+template <typename F, int... R>
+__device__ __forceinline__ void ring_for_rows(std::integer_sequence<int, R...>, F&& f)
+{ (f(std::integral_constant<int, R>{}), ...); }
 
-template <int D, int WS>
-__global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg)
+template <int D, int WS, int LPP>
+__global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg)
 {
-    using C = RingCfg<D, WS>;
-    constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS;
-    static_assert(W1 % 2 == 0, "rows go in pairs: the block size must be odd");
+    using C = RingCfg<D, WS, LPP>;
+    constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS, PPW = C::PPW;
+    // selection without transposing the lanes' slices (select_group_lds): always for four lanes per pixel
+    constexpr bool SPLIT = LPP != 2 || (RING_SPLIT_SELECT && RING_LDS_SELECT);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
     const unsigned fi = blockIdx.x;
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int phi = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int p = lane & 31, h = lane >> 5;
+    const int p = lane & (PPW - 1), h = lane / PPW;
     const int x_tile = rg.x0 + b_tile * C::TILE;
     const int x = x_tile + phi + 4 * p;
     const bool active = x < rg.x0 + rg.nx;
@@ -206,13 +216,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
 
     uint32_t* stg = lds + phi * C::WAVE_LDS;       // this wave's slice: nothing below is shared between waves
     uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][64]
-#if RING_LDS_SELECT
-    uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;   // this lane's selection record
-#if RING_SPLIT_SELECT
-    uint32_t* scr_a = stg + C::STG + p * SelRecord<D>::DWORDS + h * NRL;   // where this lane's half of the lower lane's row goes
-    uint32_t* scr_b = scr_a + 32 * SelRecord<D>::DWORDS;                   // ... and of the upper lane's row
-#endif
-#endif
+    uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;       // this lane's selection record
+    uint32_t* scr_w = stg + C::STG + p * SelRecord<D>::DWORDS + h * NRL;   // SPLIT: where this lane's slice of the group's first row goes
 
     // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
     // Unconditional loads: bytes past a row's end only ever reach lanes that are not `active`, and the prefiltered planes
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
 
-    RingState<D, WS> st;
+    RingState<D, WS, LPP> st;
 #pragma unroll
     for (int k = 0; k < W1; ++k)
 #pragma unroll
@@ -270,23 +275,24 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
     uint32_t pt = 0;                                // texture prefix sum of the rows so far
 
     const int nsteps = (ys1 - ys0) + WS - 1;
-    const int nsteps2 = (nsteps + 1) & ~1;          // rows go in pairs; a padded last row is computed and dropped
+    const int nstepsg = (nsteps + LPP - 1) / LPP * LPP;   // rows go in groups of LPP; padded last rows are computed and dropped
     issue(Set0{}); issue(Set1{});
     commit(Set0{}, 0); commit(Set1{}, 1);           // rows 0 and 1 -> slots 0 and 1
     issue(Set0{});                                  // row 2: committed at the end of step 0
 
-    // Output addresses: a wave-uniform frame base plus a 32-bit byte offset per lane that advances two rows per pair
+    // Output addresses: a wave-uniform frame base plus a 32-bit byte offset per lane that advances LPP rows per group
     // (the host checks that a frame's planes stay below 4 GB) -- no 64-bit multiply per store.
     char* const db = (char*)(disp.base + (size_t)f * disp.frame_e);
     char* const cb = (char*)(cost + (size_t)f * g.H * g.Ws);
     const int col = g.lofs + x;
-    uint32_t dofs = (uint32_t)(((size_t)(ys0 + h) * disp.pitch_e + col) * 2);     // row of the first pair with output
-    uint32_t cofs = (uint32_t)(((size_t)(ys0 + h) * g.Ws + col) * 2);
-    const uint32_t dstep = (uint32_t)(disp.pitch_e * 4), cstep = (uint32_t)(g.Ws * 4);
+    constexpr int TF = (WS - 1) / LPP * LPP;        // first group with an output row; its row h is strip row TF + h - (WS - 1)
+    uint32_t dofs = (uint32_t)(((long long)(ys0 + TF + h - (WS - 1)) * (long long)disp.pitch_e + col) * 2);   // (mod 2^32; a row
+    uint32_t cofs = (uint32_t)(((long long)(ys0 + TF + h - (WS - 1)) * (long long)g.Ws + col) * 2);           //  above the strip is never stored)
+    const uint32_t dstep = (uint32_t)(disp.pitch_e * 2 * LPP), cstep = (uint32_t)(g.Ws * 2 * LPP);
     const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
 
-    uint32_t S0[NRL], S1[NRL];
-    int ts0 = 0, ts1 = 0;
+    uint32_t S[LPP][NRL];
+    int ts[LPP];
 #ifdef RING_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
@@ -297,98 +303,91 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS>::WAVES)) void k_search_ring(Pl
     // waits for its loads).  Rows past the strip's last are loaded and staged too (clamped to the frame) and never read:
     // no branch in the step.
     int sl_cur = 0;                                 // LDS slot of row t
-    RowRegs<D, WS> ra;
-    const auto lds_row = [&](int slot, RowRegs<D, WS>& rw) {
+    const auto lds_row = [&](int slot, RowRegs<D, WS, LPP>& rw) {
         // (laundered indices: ONE base register per copy, window offsets fold into the ds_read immediates)
         int li = slot * SLOT + p, ri = slot * SLOT + LWD + p + h * NGL;
         asm volatile("" : "+v"(li), "+v"(ri));
-        ring_load_row<D, WS>(stg + li, stg + ri, rw);
+        ring_load_row<D, WS, LPP>(stg + li, stg + ri, rw);
     };
-    auto step = [&](auto Kc, const RowRegs<D, WS>& rw, uint32_t (&S)[NRL], int& ts) {
+    auto step = [&](auto Kc, const RowRegs<D, WS, LPP>& rw, uint32_t (&Sr)[NRL], int& tsr) {
         constexpr int K = decltype(Kc)::value;            // ring slot of row t: a compile-time register set
-        using SetIn = std::integral_constant<int, (K + 1) & 1>;    // row t+3 goes where row t+1 was
+        using SetIn = std::integral_constant<int, (K + 1) & 1>;    // row t+3 goes where row t+1 was (W1 is even: K and t have the same parity)
         using SetOut = std::integral_constant<int, K & 1>;         // row t+2
         issue(SetIn{});
         uint32_t tnew = 0;
-        ring_step<D, WS, K>(st, rw, rg.lastmask, capb, tnew, S);
+        ring_step<D, WS, LPP, K>(st, rw, rg.lastmask, capb, tnew, Sr);
         constexpr int KO = (K + 1) % W1;
         pt += tnew;
         const uint32_t told = ptr[KO * 64 + lane];                // prefix sum w rows back (0 while the window fills)
         ptr[K * 64 + lane] = pt;
-        ts = (int)(pt - told);
+        tsr = (int)(pt - told);
         const int sl_new = sl_cur == 0 ? 2 : sl_cur - 1;            // slot of row t+2 = (t + 2) mod 3
         sl_cur = sl_cur == 2 ? 0 : sl_cur + 1;
-        pin(S);
+        pin(Sr);
         commit(SetOut{}, sl_new);
     };
-#if RING_PRELOAD
-    lds_row(0, ra);
-#endif
 
-    // One trip of the outer loop = one round of the ring (W1 rows, W1 is even), unrolled: every row step has its ring
-    // slot -- its registers -- fixed at compile time.
-    for (int t0 = 0; t0 < nsteps2; t0 += W1) {
-        ring_for_pairs(std::make_integer_sequence<int, W1 / 2>{}, [&](auto Uc) -> bool {
-            constexpr int U = 2 * decltype(Uc)::value;
+    // One trip of the outer loop = whole rounds of the ring AND whole row groups (TRIP rows), unrolled: every row step has
+    // its ring slot -- its registers -- fixed at compile time.
+    for (int t0 = 0; t0 < nstepsg; t0 += C::TRIP) {
+        ring_for_groups(std::make_integer_sequence<int, C::TRIP / LPP>{}, [&](auto Uc) -> bool {
+            constexpr int U = LPP * decltype(Uc)::value;
             const int t = t0 + U;
-            if (t >= nsteps2) return false;
-            RING_STAMP(0);                                          // (loop overhead + whatever precedes the pair)
-#if !RING_PRELOAD
-            lds_row(sl_cur, ra);
-#endif
-            RING_STAMP(1);                                          // LDS reads of the first row (the stamp waits for them)
-            step(std::integral_constant<int, U>{}, ra, S0, ts0);
-            RING_STAMP(2);
-            {
-                RowRegs<D, WS> rb;
-                lds_row(sl_cur, rb);
-                RING_STAMP(3);
-                step(std::integral_constant<int, U + 1>{}, rb, S1, ts1);
-            }
-            RING_STAMP(4);
-#if RING_PRELOAD
-            if (t + 2 < nsteps2) lds_row(sl_cur, ra);               // the next pair's first row: in flight during the selection
-#endif
-            if (t < WS - 1) return true;                            // the window is still filling (WS - 1 is even)
-            // lanes l and l+32 hold the two halves of a pixel for rows t (S0) and t+1 (S1): after the swap the lower lane
-            // has both halves of row t and the upper lane both halves of row t+1
-#if !(RING_SPLIT_SELECT && RING_LDS_SELECT && RING_ABL == 0)
-            uint32_t rr[D / 2];
+            if (t >= nstepsg) return false;
+            RING_STAMP(0);                                          // (loop overhead + whatever precedes the group)
+            ring_for_rows(std::make_integer_sequence<int, LPP>{}, [&](auto Rc) {
+                constexpr int R = decltype(Rc)::value;
+                RowRegs<D, WS, LPP> rw;
+                lds_row(sl_cur, rw);
+                RING_STAMP(1);                                      // LDS reads of the row (the stamp waits for them)
+                step(std::integral_constant<int, (U + R) % W1>{}, rw, S[R], ts[R]);
+                RING_STAMP(2);
+            });
+            if (t + LPP - 1 < WS - 1) return true;                  // the window is still filling
+            // the lanes p + h PPW hold the LPP slices of a pixel for the rows t .. t+LPP-1; the lane with h = k owns row t+k
+            int tsum = ts[0];
 #pragma unroll
-            for (int i = 0; i < NRL; ++i) {
-#if RING_ABL == 5 || RING_ABL == 6
-                rr[i] = S0[i]; rr[NRL + i] = S1[i];
-#else
-                const auto sw = __builtin_amdgcn_permlane32_swap(S0[i], S1[i], false, false);
-                rr[i] = sw[0]; rr[NRL + i] = sw[1];
-#endif
-            }
-#endif
-            RING_STAMP(5);                                          // swaps
-            const int tsum = h ? ts1 : ts0;
+            for (int k = 1; k < LPP; ++k) tsum = h == k ? ts[k] : tsum;
             const int y = ys0 + (t - (WS - 1)) + h;
-            const bool row_ok = y < ys1;
+            const bool row_ok = y >= ys0 && y < ys1;
+            const uint32_t dof = dofs, cof = cofs;
+            dofs += dstep; cofs += cstep;
             // Selection is skipped for a wave none of whose pixels can produce a disparity here (untextured, outside the
             // tile, masked): exact, such a pixel is FILTERED and writes no cost whatever its SADs are.
             const bool dead = !active || !row_ok || masked_col || tsum < g.tex;
-            const uint32_t dof = dofs, cof = cofs;
-            dofs += dstep; cofs += cstep;
             if (__builtin_amdgcn_ballot_w64(!dead) == 0) {
                 if (active && row_ok) *(int16_t*)(db + dof) = (int16_t)g.filtered;
             } else {
                 int m1; bool fail;
-#if RING_ABL == 1 || RING_ABL == 6
-                uint32_t xo = 0;
+                int out;
+                if constexpr (SPLIT && RING_ABL == 0) {
+                    out = select_group_lds<D, LPP>(S, h, tsum, g, scr, scr_w, PPW * SelRecord<D>::DWORDS, &m1, &fail);
+                    RING_STAMP(5);
+                } else {
+                    // two lanes per pixel: after the swap the lower lane has both halves of row t and the upper lane both
+                    // halves of row t+1
+                    uint32_t rr[D / 2];
 #pragma unroll
-                for (int i = 0; i < D / 2; ++i) xo ^= rr[i];
-                const int out = (int)xo; m1 = (int)(xo >> 3); fail = (xo & 1) != 0;
-#elif RING_LDS_SELECT && RING_SPLIT_SELECT && RING_ABL == 0
-                const int out = select_split_lds<D>(S0, S1, h, tsum, g, scr, scr_a, scr_b, &m1, &fail);
-#elif RING_LDS_SELECT
-                const int out = select_disparity_lds<D>(rr, tsum, g, scr, &m1, &fail);
+                    for (int i = 0; i < NRL; ++i) {
+#if RING_ABL == 5 || RING_ABL == 6
+                        rr[i] = S[0][i]; rr[NRL + i] = S[LPP - 1][i];
 #else
-                const int out = select_disparity<D>(rr, tsum, g, &m1, &fail);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(S[0][i], S[LPP - 1][i], false, false);
+                        rr[i] = sw[0]; rr[NRL + i] = sw[1];
 #endif
+                    }
+                    RING_STAMP(5);                                  // swaps
+#if RING_ABL == 1 || RING_ABL == 6
+                    uint32_t xo = 0;
+#pragma unroll
+                    for (int i = 0; i < D / 2; ++i) xo ^= rr[i];
+                    out = (int)xo; m1 = (int)(xo >> 3); fail = (xo & 1) != 0;
+#elif RING_LDS_SELECT
+                    out = select_disparity_lds<D>(rr, tsum, g, scr, &m1, &fail);
+#else
+                    out = select_disparity<D>(rr, tsum, g, &m1, &fail);
+#endif
+                }
 #if RING_ABL == 2
                 if (active && row_ok && out == 0x12345678) {
 #else
@@ -421,24 +420,55 @@ static bool ring_range(const BMGeom& g, int* x0, int* nx)
 }
 
 // rows a strip may have so that no prefix sum leaves 16 bits: a row adds at most w * 2 cap per disparity, and a strip of
-// rs output rows walks rs + w - 1 rows plus one padded row
-static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g.w; }
+// rs output rows walks rs + w - 1 rows plus up to three padded rows (groups of four)
+static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g.w - 2; }
+
+// Instantiations: (D, blockSize, lanes per pixel).  Two lanes per pixel: every (D, blockSize) whose ring (blockSize+1) * D/4
+// registers per lane leaves room for two waves per SIMD.  Four lanes per pixel: the D = 64 ones, whose two-lane ring holds
+// them at two waves.
+#define RTDM_RING_TABLE(X) X(64, 9, 2) X(64, 7, 2) X(64, 5, 2) X(32, 7, 2) X(32, 9, 2) X(32, 11, 2) X(32, 13, 2) X(48, 7, 2) X(48, 9, 2) \
+                           X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4)
+
+static int g_ring_mode = -1;            // rtdm_debug_search_kernel: 0 never, 1 wherever instantiated, -1 default;
+static int g_ring_lpp = 0;              //   2 / 4: wherever instantiated, with that many lanes per pixel where that form exists
+void ring_set_mode(int mode) { g_ring_mode = mode < 0 ? -1 : mode == 0 ? 0 : 1; g_ring_lpp = (mode == 2 || mode == 4) ? mode : 0; }
+
+// lanes per pixel for a configuration (0: not instantiated).  RTDM_RING_LPP = 2 / 4 forces one form where it exists (A/B).
+static int ring_lpp(const BMGeom& g)
+{
+    static const int env = [] { const char* e = getenv("RTDM_RING_LPP"); return e ? atoi(e) : 0; }();
+    int have2 = 0, have4 = 0;
+#define X(DD, WW, LL) if (g.D == DD && g.w == WW) { if (LL == 2) have2 = 1; else have4 = 1; }
+    RTDM_RING_TABLE(X)
+#undef X
+    const int want = g_ring_lpp ? g_ring_lpp : env;
+    if (want == 4 && have4) return 4;
+    if (want == 2 && have2) return 2;
+    // measured (tools/ab_ring.py): four lanes per pixel win where the two-lane ring holds the kernel at two waves per SIMD
+    if (have4 && (!have2 || g.w >= 7)) return 4;
+    return have2 ? 2 : 0;
+}
+
+int ring_lanes_per_pixel(const BMGeom& g) { return ring_lpp(g); }
+
+static int ring_tile(const BMGeom& g) { return 256 / ring_lpp(g); }
 
 int ring_strips_model(const BMGeom& g, int n)
 {
     int x0 = 0, nx = 0;
-    if (!ring_range(g, &x0, &nx)) return 1;
-    const int tiles = (nx + 127) / 128, nrows = g.vy1 - g.vy0;
-    // 2 workgroups per CU resident => 512 slots; a strip pays w-1 filling rows at about half the price of an output row
-    int s = (int)(sqrtf((float)nrows * 512.0f / (0.5f * (float)(g.w - 1) * (float)tiles * (float)n)) + 0.5f);
+    if (!ring_range(g, &x0, &nx) || !ring_lpp(g)) return 1;
+    const int tile = ring_tile(g), tiles = (nx + tile - 1) / tile, nrows = g.vy1 - g.vy0;
+    // 2 (3) workgroups per CU resident => 512 (768) slots; a strip pays w-1 filling rows at about half the price of an output row
+    const float slots = tile == 128 ? 512.0f : 768.0f;
+    int s = (int)(sqrtf((float)nrows * slots / (0.5f * (float)(g.w - 1) * (float)tiles * (float)n)) + 0.5f);
     s = max(s, (nrows + ring_rows_cap(g) - 1) / ring_rows_cap(g));
     return max(1, min(s, (nrows + 15) / 16));
 }
 
-template <int D, int WS>
+template <int D, int WS, int LPP>
 static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint)
 {
-    using C = RingCfg<D, WS>;
+    using C = RingCfg<D, WS, LPP>;
     RingGeom rg;
     ring_range(g, &rg.x0, &rg.nx);
     const int rem = g.w - 4 * (C::NP - 1);
@@ -460,18 +490,12 @@ static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev >= 64 || !((done >> dev) & 1)) {
-            (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+            (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS, LPP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
             if (dev < 64) done |= 1ull << dev;
         }
     }
-    hipLaunchKernelGGL((k_search_ring<D, WS>), dim3(rg.nitems), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg);
+    hipLaunchKernelGGL((k_search_ring<D, WS, LPP>), dim3(rg.nitems), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg);
 }
-
-// Instantiations: (D, blockSize) whose ring (blockSize+1) * D/4 registers per lane leaves room for two waves per SIMD.
-#define RTDM_RING_TABLE(X) X(64, 9) X(64, 7) X(64, 5) X(32, 7) X(32, 9) X(32, 11) X(32, 13) X(48, 7) X(48, 9) X(16, 5) X(16, 7) X(16, 9)
-
-static int g_ring_mode = -1;            // rtdm_debug_search_kernel: 0 never, 1 wherever instantiated, -1 default
-void ring_set_mode(int mode) { g_ring_mode = mode; }
 
 bool ring_search_supported(const BMGeom& g)
 {
@@ -482,15 +506,13 @@ bool ring_search_supported(const BMGeom& g)
     if (ring_rows_cap(g) < 2) return false;
     if (!ring_range(g, nullptr, nullptr)) return false;
     if ((size_t)g.H * (size_t)g.Ws * 2 >= ((size_t)1 << 32)) return false;   // 32-bit byte offsets inside a frame (pitch <= Ws)
-#define X(DD, WW) if (g.D == DD && g.w == WW) return true;
-    RTDM_RING_TABLE(X)
-#undef X
-    return false;
+    return ring_lpp(g) != 0;
 }
 
 void launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint)
 {
-#define X(DD, WW) if (g.D == DD && g.w == WW) { ring_launch_one<DD, WW>(Lp, Rp, disp, cost, g, n, stream, strips_hint); return; }
+    const int lpp = ring_lpp(g);
+#define X(DD, WW, LL) if (g.D == DD && g.w == WW && lpp == LL) { ring_launch_one<DD, WW, LL>(Lp, Rp, disp, cost, g, n, stream, strips_hint); return; }
     RTDM_RING_TABLE(X)
 #undef X
 }

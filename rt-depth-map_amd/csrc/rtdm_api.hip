@@ -326,7 +326,7 @@ static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plan
     static int enabled = -1;
     if (enabled < 0) { const char* e = getenv("RTDM_AUTOTUNE"); enabled = e ? atoi(e) : 1; }
     if (!enabled || n < 16 || getenv("RTDM_FAST_WGS")) return 0;
-    TuneKey key{g.W, g.H, n, g.cx1 - g.cx0, g.vy1 - g.vy0, (fuse ? 1 : 0) | (ring ? 2 : 0)};
+    TuneKey key{g.W, g.H, n, g.cx1 - g.cx0, g.vy1 - g.vy0, (fuse ? 1 : 0) | (ring ? ring_lanes_per_pixel(g) : 0)};
     for (size_t i = 0; i < bm->tuned.size(); ++i) {
         if (!(bm->tuned[i].key == key)) continue;
         TuneEntry e = bm->tuned[i];
@@ -422,7 +422,8 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
     if (!generic_search_supported(g, &u16)) return RTDM_ERR_UNSUPPORTED;
     {
         const bool ring = fast && ring_search_supported(g);
-        bm->variant = ring ? "fast_ring_qsad" : fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
+        const int lpp = ring ? ring_lanes_per_pixel(g) : 0;
+        bm->variant = ring ? (lpp == 4 ? "fast_ring4_qsad" : "fast_ring_qsad") : fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
         Plane8W Lp{ln.dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{ln.dRp, bm->ppitch, bm->ppitch * (size_t)H};
         stage_begin(bm, RTDM_STAGE_PREFILTER, n, s, &ev);
         launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s);

@@ -62,6 +62,7 @@ void launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const B
                         int strips_hint = 0);
 int ring_strips_model(const BMGeom& g, int n);
 void ring_set_mode(int mode);   // rtdm_debug_search_kernel
+int ring_lanes_per_pixel(const BMGeom& g);   // 2 / 4: the form of k_search_ring this configuration runs (0: none)
 void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1);
 // wave-per-column kernel for those border columns (falls back to the generic kernel if unsupported)
 bool border_search_supported(const BMGeom& g);

@@ -237,42 +237,76 @@ __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2],
     return out;
 }
 
-// The LDS selection for k_search_ring's lane pairs, without transposing the SADs first.  Lanes l and l+32 (h = 0 / 1) each
-// hold one HALF of the D values -- indices [h D/2, (h+1) D/2) -- of TWO pixel rows: sa belongs to the row owned by lane l,
-// sb to the row owned by lane l+32.  Each lane writes its two halves into the owners' records, runs level one (group
-// minima and keys) and the uniqueness sums on what it holds -- the same work as for one whole row -- and only three
-// values cross between the halves (v_permlane32_swap): the partial key minima, the owners' thresholds T+1 and the
-// partial sums.  Everything after that is the owner's: winning group back from its record, argmin inside it, sad[a-1],
-// sad[a+1], the tests, the sub-pixel step.  Results are those of select_disparity_lds on the transposed values.
-//   rec_own: this lane's record; wr_a / wr_b: where this lane's halves go (record of lane l / l+32, offset h D/4 dwords).
-template <int D>
-__device__ __forceinline__ int select_split_lds(const uint32_t (&sa)[D / 4], const uint32_t (&sb)[D / 4], int h, int tsum,
-                                                const BMGeom& g, uint32_t* rec_own, uint32_t* wr_a, uint32_t* wr_b,
-                                                int* minsad, bool* rejected)
+// ---- selection for pixels whose D values are spread over LPP lanes (k_search_ring), without transposing them --------
+// The LPP lanes {p + h * 64/LPP, h = 0..LPP-1} of a wave each hold one SLICE of the D values -- indices [h D/LPP, (h+1) D/LPP)
+// -- of LPP pixel rows: S[r] belongs to the row owned by the lane with h = r.  Each lane writes its slices into the owners'
+// LDS records, runs level one (group minima and keys) and the uniqueness sums on what it holds -- in total the work of one
+// whole row -- and only three values per row cross between the lanes (v_permlane32_swap / v_permlane16_swap): the partial
+// key minima (reduced towards the owner), the owners' thresholds T+1 (broadcast back) and the partial sums (reduced).
+// Everything after that is the owner's: winning group back from its record, argmin inside it, sad[a-1], sad[a+1], the
+// tests, the sub-pixel step.  Results are those of select_disparity_lds on the gathered values.
+
+// xr_reduce: v[r] = this lane's partial value for row r; returns op over the pixel's LPP lanes of v[h] -- the full value of
+// the row this lane owns.  xr_bcast: t = the owner's value; out[r] = the value of the owner of row r, in every lane.
+template <int LPP, class Op>
+__device__ __forceinline__ uint32_t xr_reduce(const uint32_t (&v)[LPP], Op op)
 {
-    constexpr int NRL = D / 4, NGH = NRL / 4;          // registers and groups of eight per half
+    static_assert(LPP == 2 || LPP == 4, "lane bits 5 (and 4) only");
+    if constexpr (LPP == 2) {
+        // lower lane: {own v0, partner's v0}; upper lane: {partner's v1, own v1}
+        const auto s = __builtin_amdgcn_permlane32_swap(v[0], v[1], false, false);
+        return op(s[0], s[1]);
+    } else {
+        const auto s0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);   // h < 2: row 0 over {h, h+2}; h >= 2: row 2
+        const auto s1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);   //        row 1                       row 3
+        const uint32_t a = op(s0[0], s0[1]), b = op(s1[0], s1[1]);
+        const auto s2 = __builtin_amdgcn_permlane16_swap(a, b, false, false);         // even h: {own a, partner's a}; odd h: {partner's b, own b}
+        return op(s2[0], s2[1]);
+    }
+}
+template <int LPP>
+__device__ __forceinline__ void xr_bcast(uint32_t t, uint32_t (&out)[LPP])
+{
+    if constexpr (LPP == 2) {
+        const auto s = __builtin_amdgcn_permlane32_swap(t, t, false, false);
+        out[0] = s[0]; out[1] = s[1];
+    } else {
+        const auto s = __builtin_amdgcn_permlane16_swap(t, t, false, false);          // {value of the even h of the pair, of the odd h}
+        const auto se = __builtin_amdgcn_permlane32_swap(s[0], s[0], false, false);   // {h = 0, h = 2}
+        const auto so = __builtin_amdgcn_permlane32_swap(s[1], s[1], false, false);   // {h = 1, h = 3}
+        out[0] = se[0]; out[2] = se[1]; out[1] = so[0]; out[3] = so[1];
+    }
+}
+
+//   rec_own: this lane's record; wr0: where this lane's slice of row 0 goes (record of lane p, offset h D/(2 LPP) dwords);
+//   wr_stride: dwords from one row's owner record to the next (64/LPP records).
+template <int D, int LPP>
+__device__ __forceinline__ int select_group_lds(const uint32_t (&S)[LPP][D / (2 * LPP)], int h, int tsum, const BMGeom& g,
+                                                uint32_t* rec_own, uint32_t* wr0, int wr_stride, int* minsad, bool* rejected)
+{
+    constexpr int NRL = D / (2 * LPP), NGH = NRL / 4;          // registers and groups of eight per lane and row
     static_assert(D == 16 || D == 32 || D == 48 || D == 64, "record stride checked for these sizes only");
+    static_assert(NRL % 4 == 0, "a lane's slice must be whole groups of eight disparities");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-    for (int i = 0; i < NRL; i += 4) *(u4*)(wr_a + i) = u4{sa[i], sa[i + 1], sa[i + 2], sa[i + 3]};
+    for (int r = 0; r < LPP; ++r)
 #pragma unroll
-    for (int i = 0; i < NRL; i += 4) *(u4*)(wr_b + i) = u4{sb[i], sb[i + 1], sb[i + 2], sb[i + 3]};
-    // level one: key = min << 8 | group (group counted inside the half; the half's offset is added to the minimum)
-    uint32_t gma[NGH], gmb[NGH];
-    uint32_t ka = 0xffffffffu, kb = 0xffffffffu;
-#pragma unroll
-    for (int gq = 0; gq < NGH; ++gq) {
-        const uint32_t ga = sel_pk_min(sel_pk_min(sa[4 * gq], sa[4 * gq + 1]), sel_pk_min(sa[4 * gq + 2], sa[4 * gq + 3]));
-        const uint32_t gb = sel_pk_min(sel_pk_min(sb[4 * gq], sb[4 * gq + 1]), sel_pk_min(sb[4 * gq + 2], sb[4 * gq + 3]));
-        gma[gq] = ga; gmb[gq] = gb;
-        ka = min(ka, (min(ga & 0xffffu, ga >> 16) << 8) | (uint32_t)gq);
-        kb = min(kb, (min(gb & 0xffffu, gb >> 16) << 8) | (uint32_t)gq);
-    }
+        for (int i = 0; i < NRL; i += 4) *(u4*)(wr0 + r * wr_stride + i) = u4{S[r][i], S[r][i + 1], S[r][i + 2], S[r][i + 3]};
+    // level one: key = min << 8 | group (counted inside the slice; the slice's offset is added to the minimum)
+    uint32_t gm[LPP][NGH], kpart[LPP];
     const uint32_t hofs = (uint32_t)(h * NGH);
-    ka += hofs; kb += hofs;
-    // lower lane: {own ka, partner's ka}; upper lane: {partner's kb, own kb}  =>  the owner's minimum over both halves
-    const auto swk = __builtin_amdgcn_permlane32_swap(ka, kb, false, false);
-    const uint32_t kmin = min(swk[0], swk[1]);
+#pragma unroll
+    for (int r = 0; r < LPP; ++r) {
+        uint32_t k = 0xffffffffu;
+#pragma unroll
+        for (int gq = 0; gq < NGH; ++gq) {
+            const uint32_t m = sel_pk_min(sel_pk_min(S[r][4 * gq], S[r][4 * gq + 1]), sel_pk_min(S[r][4 * gq + 2], S[r][4 * gq + 3]));
+            gm[r][gq] = m;
+            k = min(k, (min(m & 0xffffu, m >> 16) << 8) | (uint32_t)gq);
+        }
+        kpart[r] = k + hofs;
+    }
+    const uint32_t kmin = xr_reduce<LPP>(kpart, [](uint32_t a, uint32_t b) { return min(a, b); });
     const int m1 = (int)(kmin >> 8);
     const int gs = (int)(kmin & 0xffu);
     const u4 grp = *(const u4*)(rec_own + 4 * gs);               // the four registers of the winning group
@@ -281,16 +315,18 @@ __device__ __forceinline__ int select_split_lds(const uint32_t (&sa)[D / 4], con
         uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
         T = min(T, 32766u);
         T1 = T + 1u;
-        const auto swt = __builtin_amdgcn_permlane32_swap(T1, T1, false, false);   // every lane: {T+1 of row a, T+1 of row b}
-        const auto usum = [&](const uint32_t (&sv)[NRL], const uint32_t (&gm)[NGH], uint32_t t1) -> uint32_t {
-            const uint32_t t1pk = t1 * 0x00010001u;
+        uint32_t t1r[LPP], zpart[LPP];
+        xr_bcast<LPP>(T1, t1r);
+#pragma unroll
+        for (int r = 0; r < LPP; ++r) {
+            const uint32_t t1pk = t1r[r] * 0x00010001u;
             uint32_t zz[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < NRL; i += 4) {
                 // a group none of whose eight values reaches the threshold in any lane adds nothing (exact)
-                if (__builtin_amdgcn_ballot_w64(sel_pk_sub_sat(t1pk, gm[i >> 2]) != 0u) == 0) continue;
-                uint32_t t0 = sel_pk_sub_sat(t1pk, sv[i]), t1v = sel_pk_sub_sat(t1pk, sv[i + 1]);
-                uint32_t t2 = sel_pk_sub_sat(t1pk, sv[i + 2]), t3 = sel_pk_sub_sat(t1pk, sv[i + 3]);
+                if (__builtin_amdgcn_ballot_w64(sel_pk_sub_sat(t1pk, gm[r][i >> 2]) != 0u) == 0) continue;
+                uint32_t t0 = sel_pk_sub_sat(t1pk, S[r][i]), t1v = sel_pk_sub_sat(t1pk, S[r][i + 1]);
+                uint32_t t2 = sel_pk_sub_sat(t1pk, S[r][i + 2]), t3 = sel_pk_sub_sat(t1pk, S[r][i + 3]);
                 asm volatile("" : "+v"(t0), "+v"(t1v), "+v"(t2), "+v"(t3));
                 zz[0] = sel_pk_add_sat(zz[0], t0); zz[1] = sel_pk_add_sat(zz[1], t1v);
                 zz[2] = sel_pk_add_sat(zz[2], t2); zz[3] = sel_pk_add_sat(zz[3], t3);
@@ -298,12 +334,9 @@ __device__ __forceinline__ int select_split_lds(const uint32_t (&sa)[D / 4], con
             const uint32_t zp = sel_pk_add_sat(sel_pk_add_sat(zz[0], zz[1]), sel_pk_add_sat(zz[2], zz[3]));
             // a 16-bit half saturates at 65535, more than the (at most two) terms of {a-1, a, a+1} it can hold add up to:
             // the total stays >= the expected total, with equality only if nothing saturated and nothing else contributed
-            return (zp & 0xffffu) + (zp >> 16);
-        };
-        const uint32_t za = usum(sa, gma, swt[0]);
-        const uint32_t zb = usum(sb, gmb, swt[1]);
-        const auto swz = __builtin_amdgcn_permlane32_swap(za, zb, false, false);    // the owner gets both halves of its row's sum
-        z = swz[0] + swz[1];
+            zpart[r] = (zp & 0xffffu) + (zp >> 16);
+        }
+        z = xr_reduce<LPP>(zpart, [](uint32_t a, uint32_t b) { return a + b; });
     }
     uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
 #pragma unroll

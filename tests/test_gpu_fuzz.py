@@ -109,27 +109,30 @@ def test_every_fast_instantiation(pkg, oracle, synth, D, pieces):
     assert np.array_equal(got, oracle.bm_compute(L, R, **kw)), (D, w)
 
 
-RING_TABLE = [(64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9)]
+RING_TABLE = [(64, 9, 2), (64, 7, 2), (64, 5, 2), (32, 7, 2), (32, 9, 2), (32, 11, 2), (32, 13, 2), (48, 7, 2), (48, 9, 2),
+              (16, 5, 2), (16, 7, 2), (16, 9, 2), (64, 9, 4), (64, 7, 4), (64, 5, 4)]
 
 
-@pytest.mark.parametrize("D,w", RING_TABLE)
-def test_every_ring_instantiation(pkg, oracle, synth, D, w):
-    # k_search_ring (prefix sums in a register ring): odd and even row counts, a strip boundary inside the frame (rows >
-    # the 16-bit cap of a strip at cap 63), ROI, negative and positive minDisparity, thresholds off
-    pkg.binding.lib().rtdm_debug_search_kernel(1)
+@pytest.mark.parametrize("D,w,lpp", RING_TABLE)
+def test_every_ring_instantiation(pkg, oracle, synth, D, w, lpp):
+    # k_search_ring (prefix sums in a register ring; two or four lanes per pixel): odd and even row counts and every
+    # remainder of the row groups, a strip boundary inside the frame (rows > the 16-bit cap of a strip at cap 63), ROI,
+    # negative and positive minDisparity, thresholds off
+    pkg.binding.lib().rtdm_debug_search_kernel(lpp)
     try:
         for k, (W, H, kw) in enumerate([
                 (D + 4 * w + 150, w + 37, {}),
                 (D + 300, 2 * w + 120, dict(preFilterCap=63 if 126 * w * w <= 32766 else 31)),
                 (D + 260, w + 46, dict(minDisparity=-3, uniquenessRatio=0, textureThreshold=0)),
                 (D + 333, w + 51, dict(minDisparity=5, disp12MaxDiff=-1, speckleWindowSize=0)),
-                (D + 400, 131, dict(roi1=(D + 20, 9, 250, 90)))]):
+                (D + 400, 131, dict(roi1=(D + 20, 9, 250, 90))),
+                (D + 70, w + 40, dict(uniquenessRatio=25)), (D + 197, w + 41, {}), (D + 64 + 2 * (w // 2), w + 42, {})]):
             L, R = synth.make_pair(synth.STREAM_SEED + 9500 + D + w + k, W, H, D)
             roi1 = kw.pop("roi1", None)
             m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, **kw)
             if roi1: m.setROI1(roi1)
             got = m.compute(L, R)
-            assert m.search_variant == "fast_ring_qsad", (D, w, m.search_variant)
+            assert m.search_variant == ("fast_ring4_qsad" if lpp == 4 else "fast_ring_qsad"), (D, w, m.search_variant)
             m.close()
             okw = dict(kw); okw.update(numDisparities=D, blockSize=w)
             if roi1: okw["roi1"] = roi1
