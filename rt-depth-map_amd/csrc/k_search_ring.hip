@@ -92,8 +92,11 @@ struct RingCfg {
     static constexpr int WAVE_LDS = STG + 64 * SelRecord<D>::DWORDS;   // + the selection's per-lane records (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
-    static constexpr int WAVES = LPP == 4 ? 3 : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
+    static constexpr int WAVES = LPP == 4 ? (RING_REGS <= 48 ? 4 : 3) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
     static constexpr int TILE = 4 * PPW;           // four byte phases
+    // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
+    // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
+    static constexpr bool ROW_PTRS = !(LPP == 2 && RING_REGS > 88 && RING_REGS <= 112);
     // rows per trip of the unrolled row loop: whole rounds of the ring AND whole groups
     static constexpr int TRIP = (W1 % LPP == 0) ? W1 : (2 * W1 % LPP == 0) ? 2 * W1 : 4 * W1;
     static_assert(W1 % 2 == 0 && TRIP % LPP == 0 && TRIP % W1 == 0, "block sizes are odd");
@@ -106,22 +109,23 @@ struct RingState { uint64_t P[RingCfg<D, WS, LPP>::W1][RingCfg<D, WS, LPP>::NGL]
 template <int D, int WS, int LPP = 2>
 struct RowRegs { uint64_t win[RingCfg<D, WS, LPP>::NW]; uint32_t l[RingCfg<D, WS, LPP>::NP]; };
 
-// lp / rp: this lane's left pieces / right windows of the staged row in LDS.
-template <int D, int WS, int LPP>
-__device__ __forceinline__ void ring_load_row(const uint32_t* __restrict__ lp, const uint32_t* __restrict__ rp, RowRegs<D, WS, LPP>& rw)
+typedef __attribute__((address_space(3))) const uint32_t* lds_cptr;    // an LDS address held as what it is: 32 bits
+__device__ __forceinline__ uint32_t lds_addr(const uint32_t* q) { return (uint32_t)(uintptr_t)(lds_cptr)q; }
+__device__ __forceinline__ lds_cptr lds_at(uint32_t a) { return (lds_cptr)(uintptr_t)a; }
+
+// lp / rp: this lane's left pieces / right windows of the staged row in LDS; rpo = rp + 1, as a pointer of its own.
+template <int D, int WS, int LPP, typename PTR>
+__device__ __forceinline__ void ring_load_row(PTR lp, PTR rp, PTR rpo, RowRegs<D, WS, LPP>& rw)
 {
     using C = RingCfg<D, WS, LPP>;
     // 64-bit operands want even-aligned VGPR pairs: windows at odd dword offsets are loaded through a second pointer
-    // whose index is laundered, so that they get their own ds_read2_b32 instead of v_mov rebuilds.
+    // (laundered by the caller), so that they get their own ds_read2_b32 instead of v_mov rebuilds.
     // Issue order = order of first use (the LDS returns data in order): the left pieces, then the windows by index.
-    int one = 1;
-    asm volatile("" : "+v"(one));
-    const uint32_t* rpo = rp + one;
 #pragma unroll
     for (int k = 0; k < C::NP; ++k) rw.l[k] = lp[k];
 #pragma unroll
     for (int j = 0; j < C::NW; ++j) {
-        const uint32_t* wp = (j & 1) ? rpo + (j - 1) : rp + j;
+        const PTR wp = (j & 1) ? rpo + (j - 1) : rp + j;
         rw.win[j] = (uint64_t)wp[0] | ((uint64_t)wp[1] << 32);
     }
 }
@@ -303,11 +307,22 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     // waits for its loads).  Rows past the strip's last are loaded and staged too (clamped to the frame) and never read:
     // no branch in the step.
     int sl_cur = 0;                                 // LDS slot of row t
-    const auto lds_row = [&](int slot, RowRegs<D, WS, LPP>& rw) {
-        // (laundered indices: ONE base register per copy, window offsets fold into the ds_read immediates)
-        int li = slot * SLOT + p, ri = slot * SLOT + LWD + p + h * NGL;
-        asm volatile("" : "+v"(li), "+v"(ri));
-        ring_load_row<D, WS, LPP>(stg + li, stg + ri, rw);
+    // this lane's read addresses in the slot of row t: three registers that move on by one slot per row (one v_add each
+    // with a wave-uniform step; laundered so that every window offset folds into a ds_read immediate of ITS base)
+    // (32-bit LDS addresses, not C++ pointers: a generic pointer that went through an asm loses its address space and
+    //  turns every read into a flat load -- measured 2x slower)
+    uint32_t la_cur = lds_addr(stg + p), ra_cur = lds_addr(stg + LWD + p + h * NGL), ro_cur = ra_cur + 4;
+    const auto lds_row = [&](RowRegs<D, WS, LPP>& rw) {
+        if constexpr (C::ROW_PTRS) {
+            asm volatile("" : "+v"(la_cur), "+v"(ra_cur), "+v"(ro_cur));
+            ring_load_row<D, WS, LPP>(lds_at(la_cur), lds_at(ra_cur), lds_at(ro_cur), rw);
+            const uint32_t adv = (uint32_t)((sl_cur == 2 ? -2 * SLOT : SLOT) * 4);   // (before the step moves sl_cur on)
+            la_cur += adv; ra_cur += adv; ro_cur += adv;
+        } else {
+            int li = sl_cur * SLOT + p, ri = sl_cur * SLOT + LWD + p + h * NGL, one = 1;
+            asm volatile("" : "+v"(li), "+v"(ri), "+v"(one));
+            ring_load_row<D, WS, LPP, const uint32_t*>(stg + li, stg + ri, stg + ri + one, rw);
+        }
     };
     auto step = [&](auto Kc, const RowRegs<D, WS, LPP>& rw, uint32_t (&Sr)[NRL], int& tsr) {
         constexpr int K = decltype(Kc)::value;            // ring slot of row t: a compile-time register set
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             ring_for_rows(std::make_integer_sequence<int, LPP>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 RowRegs<D, WS, LPP> rw;
-                lds_row(sl_cur, rw);
+                lds_row(rw);
                 RING_STAMP(1);                                      // LDS reads of the row (the stamp waits for them)
                 step(std::integral_constant<int, (U + R) % W1>{}, rw, S[R], ts[R]);
                 RING_STAMP(2);
