@@ -43,6 +43,9 @@
 #ifndef RING_LDS_SELECT   // 1: select_disparity_lds (fetches through LDS), 0: select_disparity (v_cndmask tree)
 #define RING_LDS_SELECT 1
 #endif
+#ifndef RING_STREAM_SELECT // untransposed selection: 1 GroupSelect (row by row, counting uniqueness test), 0 select_group_lds
+#define RING_STREAM_SELECT 1
+#endif
 #ifndef RING_SPLIT_SELECT // 1: select_split_lds (the halves of a lane pair are not transposed: three swaps instead of D/4).
 #define RING_SPLIT_SELECT 0 // Same results; measured within +-2 % of the transposing form on all 36 cases and 0.8 % slower on the
                             // headline (profiles/r02_ring_split_select_ab.txt): the three swaps sit on the selection's
@@ -88,11 +91,11 @@ struct RingCfg {
     static constexpr int ITEMS = (LWD + RWD + 63) / 64;
     static constexpr int SLOT = ITEMS * 64;        // padded: every lane stores every item, no exec masking
     static constexpr int NSLOT = 3;                // staged rows in flight per wave
-    static constexpr int STG = (NSLOT * SLOT + W1 * 64 + 3) & ~3;   // dwords per wave: staged rows + the texture prefix ring
+    static constexpr int STG = (NSLOT * SLOT + W1 * PPW + 3) & ~3;  // dwords per wave: staged rows + the texture prefix ring
     static constexpr int WAVE_LDS = STG + 64 * SelRecord<D>::DWORDS;   // + the selection's per-lane records (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
-    static constexpr int WAVES = LPP == 4 ? (RING_REGS <= 48 ? 4 : 3) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
+    static constexpr int WAVES = LPP == 4 ? (RING_REGS <= 64 ? 4 : 3) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
     static constexpr int TILE = 4 * PPW;           // four byte phases
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     const uint32_t capb = (uint32_t)(g.cap + 1) * 0x01010101u;
 
     uint32_t* stg = lds + phi * C::WAVE_LDS;       // this wave's slice: nothing below is shared between waves
-    uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][64]
+    uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][PPW] (the lanes of a pixel write the same value)
     uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;       // this lane's selection record
     uint32_t* scr_w = stg + C::STG + p * SelRecord<D>::DWORDS + h * NRL;   // SPLIT: where this lane's slice of the group's first row goes
 
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
 #pragma unroll
         for (int i = 0; i < NGL; ++i) st.P[k][i] = 0;
 #pragma unroll
-    for (int k = 0; k < W1; ++k) ptr[k * 64 + lane] = 0;
+    for (int k = 0; k < W1; ++k) ptr[k * PPW + p] = 0;
     uint32_t pt = 0;                                // texture prefix sum of the rows so far
 
     const int nsteps = (ys1 - ys0) + WS - 1;
@@ -333,8 +336,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
         ring_step<D, WS, LPP, K>(st, rw, rg.lastmask, capb, tnew, Sr);
         constexpr int KO = (K + 1) % W1;
         pt += tnew;
-        const uint32_t told = ptr[KO * 64 + lane];                // prefix sum w rows back (0 while the window fills)
-        ptr[K * 64 + lane] = pt;
+        const uint32_t told = ptr[KO * PPW + p];                  // prefix sum w rows back (0 while the window fills)
+        ptr[K * PPW + p] = pt;
         tsr = (int)(pt - told);
         const int sl_new = sl_cur == 0 ? 2 : sl_cur - 1;            // slot of row t+2 = (t + 2) mod 3
         sl_cur = sl_cur == 2 ? 0 : sl_cur + 1;
@@ -350,6 +353,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             const int t = t0 + U;
             if (t >= nstepsg) return false;
             RING_STAMP(0);                                          // (loop overhead + whatever precedes the group)
+            GroupSelect<D, LPP> gsel;
+            const bool has_out = t + LPP - 1 >= WS - 1;             // some row of the group has its window complete
             ring_for_rows(std::make_integer_sequence<int, LPP>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 RowRegs<D, WS, LPP> rw;
@@ -357,6 +362,10 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
                 RING_STAMP(1);                                      // LDS reads of the row (the stamp waits for them)
                 step(std::integral_constant<int, (U + R) % W1>{}, rw, S[R], ts[R]);
                 RING_STAMP(2);
+                if constexpr (SPLIT && RING_STREAM_SELECT && RING_ABL == 0) {
+                    // the row's slice goes to its owner's record and into the group minima at once: S[R] is dead after this
+                    if (has_out) gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), (uint32_t)(h * (NRL / 4)));
+                }
             });
             if (t + LPP - 1 < WS - 1) return true;                  // the window is still filling
             // the lanes p + h PPW hold the LPP slices of a pixel for the rows t .. t+LPP-1; the lane with h = k owns row t+k
@@ -375,7 +384,10 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             } else {
                 int m1; bool fail;
                 int out;
-                if constexpr (SPLIT && RING_ABL == 0) {
+                if constexpr (SPLIT && RING_STREAM_SELECT && RING_ABL == 0) {
+                    out = gsel.finish(tsum, g, scr, &m1, &fail);
+                    RING_STAMP(5);
+                } else if constexpr (SPLIT && RING_ABL == 0) {
                     out = select_group_lds<D, LPP>(S, h, tsum, g, scr, scr_w, PPW * SelRecord<D>::DWORDS, &m1, &fail);
                     RING_STAMP(5);
                 } else {
@@ -460,7 +472,7 @@ static int ring_lpp(const BMGeom& g)
     if (want == 4 && have4) return 4;
     if (want == 2 && have2) return 2;
     // measured (tools/ab_ring.py): four lanes per pixel win where the two-lane ring holds the kernel at two waves per SIMD
-    if (have4 && (!have2 || g.w >= 7)) return 4;
+    if (have4) return 4;
     return have2 ? 2 : 0;
 }
 

@@ -251,17 +251,32 @@ __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2],
 template <int LPP, class Op>
 __device__ __forceinline__ uint32_t xr_reduce(const uint32_t (&v)[LPP], Op op)
 {
-    static_assert(LPP == 2 || LPP == 4, "lane bits 5 (and 4) only");
+    static_assert(LPP == 2 || LPP == 4 || LPP == 8, "lane bits 5, 4 and 3");
     if constexpr (LPP == 2) {
         // lower lane: {own v0, partner's v0}; upper lane: {partner's v1, own v1}
         const auto s = __builtin_amdgcn_permlane32_swap(v[0], v[1], false, false);
         return op(s[0], s[1]);
-    } else {
+    } else if constexpr (LPP == 4) {
         const auto s0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);   // h < 2: row 0 over {h, h+2}; h >= 2: row 2
         const auto s1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);   //        row 1                       row 3
         const uint32_t a = op(s0[0], s0[1]), b = op(s1[0], s1[1]);
         const auto s2 = __builtin_amdgcn_permlane16_swap(a, b, false, false);         // even h: {own a, partner's a}; odd h: {partner's b, own b}
         return op(s2[0], s2[1]);
+    } else {
+        // h = lane >> 3: bit 2 = lane bit 5, bit 1 = lane bit 4, bit 0 = lane bit 3
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                                 // keeps rows (h & 4) + k, over {h, h ^ 4}
+            const auto sk = __builtin_amdgcn_permlane32_swap(v[k], v[k + 4], false, false);
+            w[k] = op(sk[0], sk[1]);
+        }
+        const auto t0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);   // keeps rows (h & 6) + 0 and + 1, over four lanes
+        const auto t1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+        const uint32_t x0 = op(t0[0], t0[1]), x1 = op(t1[0], t1[1]);
+        const bool odd = (__lane_id() & 8) != 0;
+        const uint32_t send = odd ? x0 : x1, own = odd ? x1 : x0;                     // the partner (lane ^ 8) owns the other row
+        const uint32_t recv = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)send, 0x128, 0xf, 0xf, false);   // row_ror:8
+        return op(own, recv);
     }
 }
 template <int LPP>
@@ -270,11 +285,23 @@ __device__ __forceinline__ void xr_bcast(uint32_t t, uint32_t (&out)[LPP])
     if constexpr (LPP == 2) {
         const auto s = __builtin_amdgcn_permlane32_swap(t, t, false, false);
         out[0] = s[0]; out[1] = s[1];
-    } else {
+    } else if constexpr (LPP == 4) {
         const auto s = __builtin_amdgcn_permlane16_swap(t, t, false, false);          // {value of the even h of the pair, of the odd h}
         const auto se = __builtin_amdgcn_permlane32_swap(s[0], s[0], false, false);   // {h = 0, h = 2}
         const auto so = __builtin_amdgcn_permlane32_swap(s[1], s[1], false, false);   // {h = 1, h = 3}
         out[0] = se[0]; out[2] = se[1]; out[1] = so[0]; out[3] = so[1];
+    } else {
+        const bool odd = (__lane_id() & 8) != 0;
+        const uint32_t other = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x128, 0xf, 0xf, false);     // row_ror:8: lane ^ 8
+        const uint32_t e = odd ? other : t, o = odd ? t : other;                      // rows (h & 6) + 0 and + 1
+        const auto se = __builtin_amdgcn_permlane16_swap(e, e, false, false);         // rows (h & 4) + {0, 2}
+        const auto so = __builtin_amdgcn_permlane16_swap(o, o, false, false);         //               {1, 3}
+        const uint32_t q[4] = {se[0], so[0], se[1], so[1]};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const auto sk = __builtin_amdgcn_permlane32_swap(q[k], q[k], false, false);
+            out[k] = sk[0]; out[k + 4] = sk[1];
+        }
     }
 }
 
@@ -369,5 +396,115 @@ __device__ __forceinline__ int select_group_lds(const uint32_t (&S)[LPP][D / (2 
     *rejected = fail;
     return out;
 }
+
+// The same selection, fed row by row (k_search_ring: the SADs of a row are dead as soon as its step is over, so a group of
+// LPP rows holds LPP * NGH + LPP registers of state instead of LPP * D / (2 LPP)), and with the uniqueness test split in two
+// so that it needs no SAD value again:
+//   (A) no group of eight other than the winner's and the one its neighbour a-1 / a+1 may lie in has a minimum <= T:
+//       every lane counts the groups of its slices whose minimum is <= T, the counts are reduced to the owner, and the owner
+//       expects 1 (+ 1 if the neighbour group's minimum is <= T);
+//   (B) inside those one or two groups -- read back from the owner's record -- the identity
+//       sum_e max(T+1 - sad[e], 0) == the same sum over {a-1, a, a+1}.
+// Exact: {a-1, a, a+1} lies inside the two groups, so an index outside it with sad <= T is either in another group (A) or
+// one of the up to sixteen values of (B).
+template <int D, int LPP>
+struct GroupSelect {
+    static constexpr int NRL = D / (2 * LPP), NGH = NRL / 4;
+    static_assert(D == 16 || D == 32 || D == 48 || D == 64 || D == 128, "record stride checked for these sizes only");
+    static_assert(NRL % 4 == 0, "a lane's slice must be whole groups of eight disparities");
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    uint32_t mm[LPP][NGH];      // minimum of each group of this lane's slice, per row
+    uint32_t kpart[LPP];        // min over the slice of (minimum << 8 | group), per row
+
+    // row R of the group: sv = this lane's slice of its window sums; wr = where the slice goes in the record of the row's
+    // owner; hofs = h * NGH, the number of the slice's first group
+    template <int R>
+    __device__ __forceinline__ void row(const uint32_t (&sv)[NRL], uint32_t* wr, uint32_t hofs)
+    {
+#pragma unroll
+        for (int i = 0; i < NRL; i += 4) *(u4*)(wr + i) = u4{sv[i], sv[i + 1], sv[i + 2], sv[i + 3]};
+        uint32_t k = 0xffffffffu;
+#pragma unroll
+        for (int gq = 0; gq < NGH; ++gq) {
+            const uint32_t m = sel_pk_min(sel_pk_min(sv[4 * gq], sv[4 * gq + 1]), sel_pk_min(sv[4 * gq + 2], sv[4 * gq + 3]));
+            const uint32_t m1 = min(m & 0xffffu, m >> 16);
+            mm[R][gq] = m1;
+            k = min(k, (m1 << 8) | (uint32_t)gq);
+        }
+        kpart[R] = k + hofs;
+    }
+
+    // after the LPP rows: the result for the row this lane owns (rec_own = its record)
+    __device__ __forceinline__ int finish(int tsum, const BMGeom& g, const uint32_t* rec_own, int* minsad, bool* rejected)
+    {
+        const uint32_t kmin = xr_reduce<LPP>(kpart, [](uint32_t a, uint32_t b) { return min(a, b); });
+        const int m1 = (int)(kmin >> 8);
+        const int gs = (int)(kmin & 0xffu);
+        const u4 grp = *(const u4*)(rec_own + 4 * gs);               // the four registers of the winning group
+        uint32_t T1 = 0, cnt = 0;
+        if (g.uniq > 0) {
+            uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
+            T = min(T, 32766u);
+            T1 = T + 1u;
+            uint32_t t1r[LPP], cpart[LPP];
+            xr_bcast<LPP>(T1, t1r);
+#pragma unroll
+            for (int r = 0; r < LPP; ++r) {
+                uint32_t c = 0;
+#pragma unroll
+                for (int gq = 0; gq < NGH; ++gq) c += (uint32_t)(mm[r][gq] < t1r[r]);
+                cpart[r] = c;
+            }
+            cnt = xr_reduce<LPP>(cpart, [](uint32_t a, uint32_t b) { return a + b; });
+        }
+        uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
+            const uint32_t klo = __builtin_amdgcn_perm(grp[q], ec, 0x0C050400u);
+            const uint32_t khi = __builtin_amdgcn_perm(grp[q], ec, 0x0C070601u);
+            k3[q & 1] = min(min(k3[q & 1], klo), khi);
+        }
+        const int e = (int)(min(k3[0], k3[1]) & 0xffu);
+        const int a = 8 * gs + e;
+        const bool has_n = a > 0, has_p = a + 1 < D;
+        const unsigned short* sv = (const unsigned short*)rec_own;
+        const int n_real = sv[has_n ? a - 1 : a];
+        const int p_real = sv[has_p ? a + 1 : a];
+        bool fail = tsum < g.tex;
+        if (g.uniq > 0) {
+            // the group a-1 or a+1 falls into, if that is not the winner's
+            const int nbq = (e == 0 && has_n) ? gs - 1 : (e == 7 && has_p) ? gs + 1 : gs;
+            const bool has_nb = nbq != gs;
+            const u4 nbg = *(const u4*)(rec_own + 4 * nbq);
+            const uint32_t nbm = sel_pk_min(sel_pk_min(nbg[0], nbg[1]), sel_pk_min(nbg[2], nbg[3]));
+            const uint32_t nbmin = min(nbm & 0xffffu, nbm >> 16);
+            const uint32_t expect = 1u + (uint32_t)(has_nb && nbmin < T1);
+            const uint32_t T1pk = T1 * 0x00010001u, nbmask = has_nb ? 0xffffffffu : 0u;
+            uint32_t zz[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                zz[q] = sel_pk_add_sat(sel_pk_sub_sat(T1pk, grp[q]), sel_pk_sub_sat(T1pk, nbg[q]) & nbmask);
+            const uint32_t zp = sel_pk_add_sat(sel_pk_add_sat(zz[0], zz[1]), sel_pk_add_sat(zz[2], zz[3]));
+            // a 16-bit half saturates at 65535, more than the (at most two) terms of {a-1, a, a+1} it can hold add up to:
+            // the total stays >= the expected total, with equality only if nothing saturated and nothing else contributed
+            const uint32_t z = (zp & 0xffffu) + (zp >> 16);
+            const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
+            const uint32_t want = term(m1) + (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
+            fail |= (z != want) | (cnt != expect);
+        }
+        int out = g.filtered;
+        if (!fail) {
+            const int pp = has_p ? p_real : n_real;
+            const int nn = has_n ? n_real : p_real;
+            const int den = pp + nn - 2 * m1 + abs(pp - nn);
+            const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
+            out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
+        }
+        *minsad = m1;
+        *rejected = fail;
+        return out;
+    }
+};
 
 }  // namespace rtdm
