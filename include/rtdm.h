@@ -106,8 +106,8 @@ int rtdm_bm_reset_stage_times(rtdm_bm* bm);
 /* Name of the SAD-search kernel variant the current parameters select ("generic_u16", ...). */
 const char* rtdm_bm_search_variant(const rtdm_bm* bm);
 /* Diagnostic A/B switch, process wide: which of the hand-written search kernels may be chosen for configurations that
- * several cover.  0: k_search_fast only; 1: k_search_ring where it is instantiated; 2 / 4: as 1, with two / four lanes
- * per pixel where that form of the ring kernel exists; -1 (default): the library's choice (environment RTDM_RING=0/1 and
+ * several cover.  0: k_search_fast only; 1: k_search_ring where it is instantiated; 2 / 4 / 8: as 1, with two / four / eight
+ * lanes per pixel where that form of the ring kernel exists; -1 (default): the library's choice (environment RTDM_RING=0/1 and
  * RTDM_RING_LPP=2/4 override it).  Results never depend on it. */
 void rtdm_debug_search_kernel(int mode);
 

@@ -95,7 +95,8 @@ struct RingCfg {
     static constexpr int WAVE_LDS = STG + 64 * SelRecord<D>::DWORDS;   // + the selection's per-lane records (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
-    static constexpr int WAVES = LPP == 4 ? (RING_REGS <= 64 ? 4 : 3) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;   // (tighter bounds spill)
+    // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
+    static constexpr int WAVES = LPP == 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : 3) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
@@ -197,8 +198,9 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
 {
     using C = RingCfg<D, WS, LPP>;
     constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS, PPW = C::PPW;
-    // selection without transposing the lanes' slices (select_group_lds): always for four lanes per pixel
-    constexpr bool SPLIT = LPP != 2 || (RING_SPLIT_SELECT && RING_LDS_SELECT);
+    // selection without transposing the lanes' slices (GroupSelect): always for four and eight lanes per pixel; with two
+    // lanes where it measured faster than transposing (tools/ring_split_ab.sh, profiles/r02_ring_split_select_ab.txt)
+    constexpr bool SPLIT = LPP != 2 || D >= 48 || (D == 32 && WS == 9) || (RING_SPLIT_SELECT && RING_LDS_SELECT);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
     const unsigned fi = blockIdx.x;
@@ -299,7 +301,6 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
 
     uint32_t S[LPP][NRL];
-    int ts[LPP];
 #ifdef RING_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
@@ -355,12 +356,15 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             RING_STAMP(0);                                          // (loop overhead + whatever precedes the group)
             GroupSelect<D, LPP> gsel;
             const bool has_out = t + LPP - 1 >= WS - 1;             // some row of the group has its window complete
+            int tsum = 0;
             ring_for_rows(std::make_integer_sequence<int, LPP>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 RowRegs<D, WS, LPP> rw;
                 lds_row(rw);
                 RING_STAMP(1);                                      // LDS reads of the row (the stamp waits for them)
-                step(std::integral_constant<int, (U + R) % W1>{}, rw, S[R], ts[R]);
+                int tsr;
+                step(std::integral_constant<int, (U + R) % W1>{}, rw, S[R], tsr);
+                tsum = (R == 0 || h == R) ? tsr : tsum;             // the texture sum of the row this lane owns
                 RING_STAMP(2);
                 if constexpr (SPLIT && RING_STREAM_SELECT && RING_ABL == 0) {
                     // the row's slice goes to its owner's record and into the group minima at once: S[R] is dead after this
@@ -369,9 +373,6 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             });
             if (t + LPP - 1 < WS - 1) return true;                  // the window is still filling
             // the lanes p + h PPW hold the LPP slices of a pixel for the rows t .. t+LPP-1; the lane with h = k owns row t+k
-            int tsum = ts[0];
-#pragma unroll
-            for (int k = 1; k < LPP; ++k) tsum = h == k ? ts[k] : tsum;
             const int y = ys0 + (t - (WS - 1)) + h;
             const bool row_ok = y >= ys0 && y < ys1;
             const uint32_t dof = dofs, cof = cofs;
@@ -447,33 +448,31 @@ static bool ring_range(const BMGeom& g, int* x0, int* nx)
 }
 
 // rows a strip may have so that no prefix sum leaves 16 bits: a row adds at most w * 2 cap per disparity, and a strip of
-// rs output rows walks rs + w - 1 rows plus up to three padded rows (groups of four)
-static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g.w - 2; }
+// rs output rows walks rs + w - 1 rows plus up to seven padded rows (groups of eight)
+static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g.w - 6; }
 
 // Instantiations: (D, blockSize, lanes per pixel).  Two lanes per pixel: every (D, blockSize) whose ring (blockSize+1) * D/4
 // registers per lane leaves room for two waves per SIMD.  Four lanes per pixel: the D = 64 ones, whose two-lane ring holds
-// them at two waves.
+// them at two waves (D = 32 with four lanes measured 0-8 % slower than with two: not instantiated).  Eight lanes: D = 128.
 #define RTDM_RING_TABLE(X) X(64, 9, 2) X(64, 7, 2) X(64, 5, 2) X(32, 7, 2) X(32, 9, 2) X(32, 11, 2) X(32, 13, 2) X(48, 7, 2) X(48, 9, 2) \
-                           X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4)
+                           X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4) X(128, 7, 8) X(128, 9, 8) X(128, 11, 8)
 
 static int g_ring_mode = -1;            // rtdm_debug_search_kernel: 0 never, 1 wherever instantiated, -1 default;
 static int g_ring_lpp = 0;              //   2 / 4: wherever instantiated, with that many lanes per pixel where that form exists
-void ring_set_mode(int mode) { g_ring_mode = mode < 0 ? -1 : mode == 0 ? 0 : 1; g_ring_lpp = (mode == 2 || mode == 4) ? mode : 0; }
+void ring_set_mode(int mode) { g_ring_mode = mode < 0 ? -1 : mode == 0 ? 0 : 1; g_ring_lpp = (mode == 2 || mode == 4 || mode == 8) ? mode : 0; }
 
 // lanes per pixel for a configuration (0: not instantiated).  RTDM_RING_LPP = 2 / 4 forces one form where it exists (A/B).
 static int ring_lpp(const BMGeom& g)
 {
     static const int env = [] { const char* e = getenv("RTDM_RING_LPP"); return e ? atoi(e) : 0; }();
-    int have2 = 0, have4 = 0;
-#define X(DD, WW, LL) if (g.D == DD && g.w == WW) { if (LL == 2) have2 = 1; else have4 = 1; }
+    int have = 0;                          // bit mask of the forms instantiated for (D, w)
+#define X(DD, WW, LL) if (g.D == DD && g.w == WW) have |= LL;
     RTDM_RING_TABLE(X)
 #undef X
     const int want = g_ring_lpp ? g_ring_lpp : env;
-    if (want == 4 && have4) return 4;
-    if (want == 2 && have2) return 2;
-    // measured (tools/ab_ring.py): four lanes per pixel win where the two-lane ring holds the kernel at two waves per SIMD
-    if (have4) return 4;
-    return have2 ? 2 : 0;
+    if (want && (have & want) == want) return want;
+    // measured (tools/ab_ring.py): more lanes per pixel win where the ring holds the two-lane form at two waves per SIMD
+    return (have & 8) ? 8 : (have & 4) ? 4 : (have & 2) ? 2 : 0;
 }
 
 int ring_lanes_per_pixel(const BMGeom& g) { return ring_lpp(g); }
@@ -486,7 +485,7 @@ int ring_strips_model(const BMGeom& g, int n)
     if (!ring_range(g, &x0, &nx) || !ring_lpp(g)) return 1;
     const int tile = ring_tile(g), tiles = (nx + tile - 1) / tile, nrows = g.vy1 - g.vy0;
     // 2 (3) workgroups per CU resident => 512 (768) slots; a strip pays w-1 filling rows at about half the price of an output row
-    const float slots = tile == 128 ? 512.0f : 768.0f;
+    const float slots = tile == 64 ? 768.0f : 512.0f;
     int s = (int)(sqrtf((float)nrows * slots / (0.5f * (float)(g.w - 1) * (float)tiles * (float)n)) + 0.5f);
     s = max(s, (nrows + ring_rows_cap(g) - 1) / ring_rows_cap(g));
     return max(1, min(s, (nrows + 15) / 16));

@@ -110,7 +110,8 @@ def test_every_fast_instantiation(pkg, oracle, synth, D, pieces):
 
 
 RING_TABLE = [(64, 9, 2), (64, 7, 2), (64, 5, 2), (32, 7, 2), (32, 9, 2), (32, 11, 2), (32, 13, 2), (48, 7, 2), (48, 9, 2),
-              (16, 5, 2), (16, 7, 2), (16, 9, 2), (64, 9, 4), (64, 7, 4), (64, 5, 4)]
+              (16, 5, 2), (16, 7, 2), (16, 9, 2), (64, 9, 4), (64, 7, 4), (64, 5, 4), (128, 7, 8), (128, 9, 8),
+              (128, 11, 8)]
 
 
 @pytest.mark.parametrize("D,w,lpp", RING_TABLE)
@@ -132,7 +133,7 @@ def test_every_ring_instantiation(pkg, oracle, synth, D, w, lpp):
             m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, **kw)
             if roi1: m.setROI1(roi1)
             got = m.compute(L, R)
-            assert m.search_variant == ("fast_ring4_qsad" if lpp == 4 else "fast_ring_qsad"), (D, w, m.search_variant)
+            assert m.search_variant == {2: "fast_ring_qsad", 4: "fast_ring4_qsad", 8: "fast_ring8_qsad"}[lpp], (D, w, m.search_variant)
             m.close()
             okw = dict(kw); okw.update(numDisparities=D, blockSize=w)
             if roi1: okw["roi1"] = roi1

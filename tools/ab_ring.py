@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B of the hand-written search kernels (run on the GPU box): search-stage time per launch of k_search_fast (mode 0) and
-k_search_ring with two and four lanes per pixel (modes 2, 4) for every configuration the ring kernel is instantiated for."""
+k_search_ring with two, four and eight lanes per pixel (modes 2, 4, 8) for every configuration the ring kernel is instantiated for."""
 import importlib, json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,13 +9,14 @@ lib = pkg.binding.lib()
 st = torch.cuda.current_stream().cuda_stream
 out = {}
 for (W, H, B) in ((1280, 720, 64), (640, 480, 128), (320, 240, 256)):
-    for (D, w) in ((64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9)):
+    for (D, w) in ((64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9),
+                   (128, 7), (128, 9), (128, 11)):
         dL = torch.empty((B, H, W), dtype=torch.uint8, device="cuda"); dR = torch.empty_like(dL)
         dD = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
         pkg.synth_pairs_device(dL, dR, first_frame=0, numDisparities=D, stream=st)
         res = {}
         ref = None
-        for mode in (0, 2, 4):
+        for mode in (0, 2, 4, 8):
             lib.rtdm_debug_search_kernel(mode)
             m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=B)
             for _ in range(3): m.compute_device(dL, dR, dD, st)
