@@ -355,7 +355,6 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             if (t >= nstepsg) return false;
             RING_STAMP(0);                                          // (loop overhead + whatever precedes the group)
             GroupSelect<D, LPP> gsel;
-            const bool has_out = t + LPP - 1 >= WS - 1;             // some row of the group has its window complete
             int tsum = 0;
             ring_for_rows(std::make_integer_sequence<int, LPP>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
@@ -368,7 +367,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
                 RING_STAMP(2);
                 if constexpr (SPLIT && RING_STREAM_SELECT && RING_ABL == 0) {
                     // the row's slice goes to its owner's record and into the group minima at once: S[R] is dead after this
-                    if (has_out) gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), (uint32_t)(h * (NRL / 4)));
+                    // (also while the window fills: a branch around it turns into selects on all of gsel's state)
+                    gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), (uint32_t)(h * (NRL / 4)));
                 }
             });
             if (t + LPP - 1 < WS - 1) return true;                  // the window is still filling
