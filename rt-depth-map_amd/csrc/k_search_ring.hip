@@ -96,7 +96,7 @@ struct RingCfg {
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
     // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
-    static constexpr int WAVES = LPP == 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : 3) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;
+    static constexpr int WAVES = LPP == 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : RING_REGS <= 96 ? 3 : 2) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
@@ -455,7 +455,8 @@ static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g
 // registers per lane leaves room for two waves per SIMD.  Four lanes per pixel: the D = 64 ones, whose two-lane ring holds
 // them at two waves (D = 32 with four lanes measured 0-8 % slower than with two: not instantiated).  Eight lanes: D = 128.
 #define RTDM_RING_TABLE(X) X(64, 9, 2) X(64, 7, 2) X(64, 5, 2) X(32, 7, 2) X(32, 9, 2) X(32, 11, 2) X(32, 13, 2) X(48, 7, 2) X(48, 9, 2) \
-                           X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4) X(128, 7, 8) X(128, 9, 8) X(128, 11, 8)
+                           X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4) X(64, 11, 4) X(64, 13, 4) \
+                           X(128, 7, 8) X(128, 9, 8) X(128, 11, 8) X(128, 13, 8)
 
 static int g_ring_mode = -1;            // rtdm_debug_search_kernel: 0 never, 1 wherever instantiated, -1 default;
 static int g_ring_lpp = 0;              //   2 / 4: wherever instantiated, with that many lanes per pixel where that form exists
