@@ -7,21 +7,28 @@
 //       S(t)[d] = P(t)[d] - P(t-w)[d]                   the w x w window sum
 // in a ring of w+1 register slots: v_qsad_pk_u16_u8 takes P(t-1) as its accumulator operand and writes P(t) into the
 // slot of the dead P(t-w-1), so a row costs its quad-SADs once plus one subtraction per two disparities.  Ring slots
-// are compile-time registers: one trip of the row loop is one round of the ring, unrolled, every row step a copy with
-// its own register operands (a switch over the slot inside a rolled loop made the register allocator copy and spill
+// are compile-time registers: one trip of the row loop is a whole number of rounds of the ring, unrolled, every row step a
+// copy with its own register operands (a switch over the slot inside a rolled loop made the register allocator copy and spill
 // the ring at every merge).
 //
-// A pixel's ring is (w+1) * D/2 registers (320 at D = 64, w = 9), so the D disparities of a pixel are split over the TWO
-// lanes l and l+32 of a wave (160 ring registers each, 2 waves per SIMD).  Selection wants all D values of a pixel in
-// one lane: rows are processed in PAIRS, and after the pair one v_permlane32_swap per register hands the lower lane both
-// halves of row t and the upper lane both halves of row t+1 -- each lane then runs the single-lane selection of
-// rtdm_select.h once per two rows, so nothing is computed twice.
+// A pixel's ring is (w+1) * D/2 registers (320 at D = 64, w = 9), so the D disparities of a pixel are split over LPP lanes
+// of a wave -- p + h * 64/LPP, h = 0..LPP-1, each with a slice of D/LPP disparities -- and rows are processed in GROUPS of LPP:
+// the lane with h = k owns row k of the group and produces its output pixel.
+//   LPP = 2 (D <= 48; D = 64 as an A/B form): ring 160 registers at D = 64, w = 9 => two waves per SIMD
+//   LPP = 4 (D = 64): ring 80 registers, 148 VGPRs => three waves (four for w <= 7)
+//   LPP = 8 (D = 128): ring 96 registers at w = 11; two waves (the selection records, 17 KB per wave, allow no more)
+// Selection wants all D values of a pixel in one place.  Two forms (rtdm_select.h):
+//   * transposing (LPP = 2, D <= 32): one v_permlane32_swap per register hands the lower lane both halves of row t and the
+//     upper lane both halves of row t+1; each lane runs the single-lane selection select_disparity_lds;
+//   * GroupSelect (everything else): nothing is transposed.  Each lane writes its slice of a row into the owner's LDS
+//     record and folds it into per-group minima as soon as the row's step is over (the SADs are dead after that), and per
+//     row only three words cross between the lanes: partial key minima, thresholds, partial counts.
 //
-// Mapping: workgroup = 128 output columns x `rs` rows of one frame; wave = byte phase phi, lanes l and l+32 = column
-// x_tile + phi + 4 (l & 31).  The four waves never synchronise: each stages ITS byte-shifted copy of the entering rows
-// (128 dwords at D = 64, padded) into its own LDS slice, two rows ahead of their use, and the LDS queue of a wave is in
-// order.  The texture sum is a prefix ring too (one dword per lane and slot, in LDS).  Only columns whose window needs
-// no border clamping are handled here; the border columns go to k_search_border.
+// Mapping: workgroup = 4 * 64/LPP output columns x `rs` rows of one frame; wave = byte phase phi, lane (p, h) = column
+// x_tile + phi + 4 p.  The four waves never synchronise: each stages ITS byte-shifted copy of the entering rows (64 or 128
+// dwords, padded) into its own LDS slice, two rows ahead of their use, and the LDS queue of a wave is in order.  The
+// texture sum is a prefix ring too (one dword per pixel and slot, in LDS).  Only columns whose window needs no border
+// clamping are handled here; the border columns go to k_search_border.
 // Semantics: SURVEY.md Appendix A.3b; oracle: oracle/bm_oracle.c.
 //
 // Measured instruction costs on gfx950 that shaped this (tools/ubench_valu.hip, SIMD cycles per wave-instruction):
@@ -34,23 +41,15 @@
 #include <type_traits>
 #include <utility>
 
-#ifndef RING_PRELOAD      // 1: the first row of the next pair is read from LDS before the selection (needs ~25 more VGPRs)
-#define RING_PRELOAD 0
-#endif
 #ifndef RING_ABL          // timing-only ablations (tools/ring_ablate.sh): 1 no selection, 2 no stores, 3 no global loads,
 #define RING_ABL 0        // 4 no quad-SADs, 5 no swaps, 6 no swaps + no selection.  Outputs are wrong for n != 0.
 #endif
 #ifndef RING_LDS_SELECT   // 1: select_disparity_lds (fetches through LDS), 0: select_disparity (v_cndmask tree)
 #define RING_LDS_SELECT 1
 #endif
-#ifndef RING_STREAM_SELECT // untransposed selection: 1 GroupSelect (row by row, counting uniqueness test), 0 select_group_lds
-#define RING_STREAM_SELECT 1
-#endif
-#ifndef RING_SPLIT_SELECT // 1: select_split_lds (the halves of a lane pair are not transposed: three swaps instead of D/4).
-#define RING_SPLIT_SELECT 0 // Same results; measured within +-2 % of the transposing form on all 36 cases and 0.8 % slower on the
-                            // headline (profiles/r02_ring_split_select_ab.txt): the three swaps sit on the selection's
-                            // dependency chain, the D/4 of the transposing form pipeline.  tools/ring_split_ab.sh
-#endif
+#ifndef RING_SPLIT_SELECT // 1: GroupSelect also for the two-lane configurations that default to the transposing selection
+#define RING_SPLIT_SELECT 0 // (D = 16, D = 32 except w = 9: measured 0-8 % slower there, profiles/r02_ring_split_select_ab.txt;
+#endif                      //  tools/ring_split_ab.sh)
 
 #ifdef RING_STAMPS        // diagnostic build only (tools/ring_stamps.sh): where a row pair spends its cycles
 __device__ unsigned long long ring_stamps[8];
@@ -365,7 +364,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
                 step(std::integral_constant<int, (U + R) % W1>{}, rw, S[R], tsr);
                 tsum = (R == 0 || h == R) ? tsr : tsum;             // the texture sum of the row this lane owns
                 RING_STAMP(2);
-                if constexpr (SPLIT && RING_STREAM_SELECT && RING_ABL == 0) {
+                if constexpr (SPLIT && RING_ABL == 0) {
                     // the row's slice goes to its owner's record and into the group minima at once: S[R] is dead after this
                     // (also while the window fills: a branch around it turns into selects on all of gsel's state)
                     gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), (uint32_t)(h * (NRL / 4)));
@@ -385,11 +384,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             } else {
                 int m1; bool fail;
                 int out;
-                if constexpr (SPLIT && RING_STREAM_SELECT && RING_ABL == 0) {
+                if constexpr (SPLIT && RING_ABL == 0) {
                     out = gsel.finish(tsum, g, scr, &m1, &fail);
-                    RING_STAMP(5);
-                } else if constexpr (SPLIT && RING_ABL == 0) {
-                    out = select_group_lds<D, LPP>(S, h, tsum, g, scr, scr_w, PPW * SelRecord<D>::DWORDS, &m1, &fail);
                     RING_STAMP(5);
                 } else {
                     // two lanes per pixel: after the swap the lower lane has both halves of row t and the upper lane both

@@ -244,7 +244,9 @@ __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2],
 // whole row -- and only three values per row cross between the lanes (v_permlane32_swap / v_permlane16_swap): the partial
 // key minima (reduced towards the owner), the owners' thresholds T+1 (broadcast back) and the partial sums (reduced).
 // Everything after that is the owner's: winning group back from its record, argmin inside it, sad[a-1], sad[a+1], the
-// tests, the sub-pixel step.  Results are those of select_disparity_lds on the gathered values.
+// tests, the sub-pixel step.  Results are those of select_disparity_lds on the gathered values.  (A first version kept the
+// slices in registers and evaluated the sum identity of select_disparity_lds on them: 13 % more instructions and 10 more
+// VGPRs at D = 64, four lanes, 0.968 vs 1.018 ms per 64 pairs.)
 
 // xr_reduce: v[r] = this lane's partial value for row r; returns op over the pixel's LPP lanes of v[h] -- the full value of
 // the row this lane owns.  xr_bcast: t = the owner's value; out[r] = the value of the owner of row r, in every lane.
@@ -305,101 +307,9 @@ __device__ __forceinline__ void xr_bcast(uint32_t t, uint32_t (&out)[LPP])
     }
 }
 
-//   rec_own: this lane's record; wr0: where this lane's slice of row 0 goes (record of lane p, offset h D/(2 LPP) dwords);
-//   wr_stride: dwords from one row's owner record to the next (64/LPP records).
-template <int D, int LPP>
-__device__ __forceinline__ int select_group_lds(const uint32_t (&S)[LPP][D / (2 * LPP)], int h, int tsum, const BMGeom& g,
-                                                uint32_t* rec_own, uint32_t* wr0, int wr_stride, int* minsad, bool* rejected)
-{
-    constexpr int NRL = D / (2 * LPP), NGH = NRL / 4;          // registers and groups of eight per lane and row
-    static_assert(D == 16 || D == 32 || D == 48 || D == 64, "record stride checked for these sizes only");
-    static_assert(NRL % 4 == 0, "a lane's slice must be whole groups of eight disparities");
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-    for (int r = 0; r < LPP; ++r)
-#pragma unroll
-        for (int i = 0; i < NRL; i += 4) *(u4*)(wr0 + r * wr_stride + i) = u4{S[r][i], S[r][i + 1], S[r][i + 2], S[r][i + 3]};
-    // level one: key = min << 8 | group (counted inside the slice; the slice's offset is added to the minimum)
-    uint32_t gm[LPP][NGH], kpart[LPP];
-    const uint32_t hofs = (uint32_t)(h * NGH);
-#pragma unroll
-    for (int r = 0; r < LPP; ++r) {
-        uint32_t k = 0xffffffffu;
-#pragma unroll
-        for (int gq = 0; gq < NGH; ++gq) {
-            const uint32_t m = sel_pk_min(sel_pk_min(S[r][4 * gq], S[r][4 * gq + 1]), sel_pk_min(S[r][4 * gq + 2], S[r][4 * gq + 3]));
-            gm[r][gq] = m;
-            k = min(k, (min(m & 0xffffu, m >> 16) << 8) | (uint32_t)gq);
-        }
-        kpart[r] = k + hofs;
-    }
-    const uint32_t kmin = xr_reduce<LPP>(kpart, [](uint32_t a, uint32_t b) { return min(a, b); });
-    const int m1 = (int)(kmin >> 8);
-    const int gs = (int)(kmin & 0xffu);
-    const u4 grp = *(const u4*)(rec_own + 4 * gs);               // the four registers of the winning group
-    uint32_t z = 0, T1 = 0;
-    if (g.uniq > 0) {
-        uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
-        T = min(T, 32766u);
-        T1 = T + 1u;
-        uint32_t t1r[LPP], zpart[LPP];
-        xr_bcast<LPP>(T1, t1r);
-#pragma unroll
-        for (int r = 0; r < LPP; ++r) {
-            const uint32_t t1pk = t1r[r] * 0x00010001u;
-            uint32_t zz[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int i = 0; i < NRL; i += 4) {
-                // a group none of whose eight values reaches the threshold in any lane adds nothing (exact)
-                if (__builtin_amdgcn_ballot_w64(sel_pk_sub_sat(t1pk, gm[r][i >> 2]) != 0u) == 0) continue;
-                uint32_t t0 = sel_pk_sub_sat(t1pk, S[r][i]), t1v = sel_pk_sub_sat(t1pk, S[r][i + 1]);
-                uint32_t t2 = sel_pk_sub_sat(t1pk, S[r][i + 2]), t3 = sel_pk_sub_sat(t1pk, S[r][i + 3]);
-                asm volatile("" : "+v"(t0), "+v"(t1v), "+v"(t2), "+v"(t3));
-                zz[0] = sel_pk_add_sat(zz[0], t0); zz[1] = sel_pk_add_sat(zz[1], t1v);
-                zz[2] = sel_pk_add_sat(zz[2], t2); zz[3] = sel_pk_add_sat(zz[3], t3);
-            }
-            const uint32_t zp = sel_pk_add_sat(sel_pk_add_sat(zz[0], zz[1]), sel_pk_add_sat(zz[2], zz[3]));
-            // a 16-bit half saturates at 65535, more than the (at most two) terms of {a-1, a, a+1} it can hold add up to:
-            // the total stays >= the expected total, with equality only if nothing saturated and nothing else contributed
-            zpart[r] = (zp & 0xffffu) + (zp >> 16);
-        }
-        z = xr_reduce<LPP>(zpart, [](uint32_t a, uint32_t b) { return a + b; });
-    }
-    uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
-        const uint32_t klo = __builtin_amdgcn_perm(grp[q], ec, 0x0C050400u);
-        const uint32_t khi = __builtin_amdgcn_perm(grp[q], ec, 0x0C070601u);
-        k3[q & 1] = min(min(k3[q & 1], klo), khi);
-    }
-    const int a = 8 * gs + (int)(min(k3[0], k3[1]) & 0xffu);
-    const bool has_n = a > 0, has_p = a + 1 < D;
-    const unsigned short* sv = (const unsigned short*)rec_own;
-    const int n_real = sv[has_n ? a - 1 : a];
-    const int p_real = sv[has_p ? a + 1 : a];
-    bool fail = tsum < g.tex;
-    if (g.uniq > 0) {
-        const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
-        const uint32_t want = term(m1) + (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
-        fail |= z != want;
-    }
-    int out = g.filtered;
-    if (!fail) {
-        const int pp = has_p ? p_real : n_real;
-        const int nn = has_n ? n_real : p_real;
-        const int den = pp + nn - 2 * m1 + abs(pp - nn);
-        const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
-        out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
-    }
-    *minsad = m1;
-    *rejected = fail;
-    return out;
-}
-
-// The same selection, fed row by row (k_search_ring: the SADs of a row are dead as soon as its step is over, so a group of
-// LPP rows holds LPP * NGH + LPP registers of state instead of LPP * D / (2 LPP)), and with the uniqueness test split in two
-// so that it needs no SAD value again:
+// GroupSelect is fed row by row (k_search_ring: the SADs of a row are dead as soon as its step is over, so a group of LPP
+// rows holds LPP * NGH + LPP registers of state instead of LPP * D / (2 LPP)), with the uniqueness test split in two so that
+// it needs no SAD value a second time:
 //   (A) no group of eight other than the winner's and the one its neighbour a-1 / a+1 may lie in has a minimum <= T:
 //       every lane counts the groups of its slices whose minimum is <= T, the counts are reduced to the owner, and the owner
 //       expects 1 (+ 1 if the neighbour group's minimum is <= T);

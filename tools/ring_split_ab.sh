@@ -1,6 +1,6 @@
 #!/bin/bash
-# A/B of the ring kernel's selection (run on the GPU box): RING_SPLIT_SELECT=0 (transpose the lane pairs' halves with D/4
-# v_permlane32_swap, then select_disparity_lds) against the default select_split_lds, all twelve instantiations x 3 frame sizes.
+# A/B of the two-lane ring kernel's selection (run on the GPU box): -DRING_SPLIT_SELECT=0 = the per-configuration default
+# (transposing selection for D = 16 and D = 32 except w = 9, GroupSelect elsewhere), =1 = GroupSelect everywhere.
 R=$GRAFT_REPO_ROOT
 cd $R/rt-depth-map_amd
 for V in "-DRING_SPLIT_SELECT=0" "-DRING_SPLIT_SELECT=1"; do
