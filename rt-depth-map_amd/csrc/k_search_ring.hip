@@ -72,6 +72,7 @@ struct RingGeom {
     uint32_t lastmask;   // byte mask of the last (partial) window piece
     int tiles, strips;   // column tiles x row strips per frame
     unsigned nitems;     // workgroups over the whole batch
+    unsigned chunk;      // ceil(nitems / 8): consecutive items one XCD works through (0: no remapping)
 };
 
 // LPP = lanes per pixel: the D disparities of a pixel are split over LPP lanes of a wave (p + h * 64/LPP, h = 0..LPP-1), and
@@ -202,7 +203,11 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     constexpr bool SPLIT = LPP != 2 || D >= 48 || (D == 32 && WS == 9) || (RING_SPLIT_SELECT && RING_LDS_SELECT);
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
-    const unsigned fi = blockIdx.x;
+    // Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Item = (frame, strip, tile), tile fastest:
+    // XCD k takes the items [k chunk, (k+1) chunk) in order, so the tiles of a strip -- which share their D + w column halo
+    // -- and the strips of a frame -- which share w-1 rows -- meet in ONE L2 instead of being fetched into eight.
+    unsigned fi = blockIdx.x;
+    if (rg.chunk) fi = (fi & 7u) * rg.chunk + (fi >> 3);
     if (fi >= rg.nitems) return;
     const int b_tile = (int)(fi % rg.tiles), b_strip = (int)((fi / rg.tiles) % rg.strips), f = (int)(fi / (rg.tiles * rg.strips));
 
@@ -506,6 +511,9 @@ static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
     strips = (nrows + rg.rs - 1) / rg.rs;
     rg.tiles = tiles; rg.strips = strips;
     rg.nitems = (unsigned)tiles * strips * n;
+    static const bool xcd_local = [] { const char* e = getenv("RTDM_RING_XCD"); return !e || atoi(e) != 0; }();   // A/B switch
+    rg.chunk = xcd_local ? (rg.nitems + 7) / 8 : 0;
+    const unsigned grid = rg.chunk ? rg.chunk * 8 : rg.nitems;
     static const size_t ldspad = [] { const char* e = getenv("RTDM_RING_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
     const size_t ldsb = (size_t)4 * C::WAVE_LDS * sizeof(uint32_t) + ldspad;   // (padding: occupancy experiments)
     if (ldsb > 48 * 1024) {                         // once per device of this process (a handle lives on one device)
@@ -517,7 +525,7 @@ static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
             if (dev < 64) done |= 1ull << dev;
         }
     }
-    hipLaunchKernelGGL((k_search_ring<D, WS, LPP>), dim3(rg.nitems), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg);
+    hipLaunchKernelGGL((k_search_ring<D, WS, LPP>), dim3(grid), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg);
 }
 
 bool ring_search_supported(const BMGeom& g)
