@@ -46,14 +46,16 @@ class HIPMatcher:
     def filtered(self):
         return (self.params.minDisparity - 1) * 16
 
-    def compute(self, left, right):
-        """left/right: 2-D uint8 numpy arrays (row stride free, column stride 1) -> int16 HxW (x16)."""
+    def compute(self, left, right, out=None):
+        """left/right: 2-D uint8 numpy arrays (row stride free, column stride 1) -> int16 HxW (x16).
+        out: an int16 HxW array (column stride 1) to write into -- what a caller that keeps its cv::Mat does."""
         assert left.dtype == np.uint8 and right.dtype == np.uint8 and left.shape == right.shape
         assert left.ndim == 2 and left.strides[1] == 1 and right.strides[1] == 1
         H, W = left.shape
-        disp = np.empty((H, W), np.int16)
+        disp = np.empty((H, W), np.int16) if out is None else out
+        assert disp.dtype == np.int16 and disp.shape == (H, W) and disp.strides[1] == 2
         B.check(B.lib().rtdm_bm_compute(self._h, left.ctypes.data, left.strides[0], right.ctypes.data,
-                                        right.strides[0], W, H, disp.ctypes.data, W * 2), "rtdm_bm_compute")
+                                        right.strides[0], W, H, disp.ctypes.data, disp.strides[0]), "rtdm_bm_compute")
         return disp
 
     def compute_depth(self, left, right, Q, mask, regions, calibration_unit=25.0, want_disp=False):

@@ -117,3 +117,33 @@ def test_roi_moving_batched_caller_keeps_flat_call_time(pkg, synth):
     # a tuning pass is ~30 extra launches and shows up as a >10x outlier; growth with the ROI area is < 4x over the run
     assert t.max() < 6 * np.median(t), times
     m.close()
+
+
+# ---- the opt-in two-lane mode (RTDM_LANES=2): pieces on two workspace slices, row kernels on a back stream ------------
+def test_two_lane_pipeline_matches_the_oracle():
+    code = r'''
+import importlib, sys, numpy as np, torch
+sys.path.insert(0, %r)
+pkg = importlib.import_module("rt-depth-map_amd")
+from oracle import oracle as orc
+orc.build()
+n, W, H, D, w = 22, 400, 150, 64, 9
+Ls, Rs = pkg.synth.make_stream(31, n, W, H, D)
+dL, dR = torch.from_numpy(Ls).cuda(), torch.from_numpy(Rs).cuda()
+dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n)
+st = torch.cuda.current_stream().cuda_stream
+for rep in range(3):                       # the autotuned strip count comes in on the later calls
+    dD.fill_(777)
+    m.compute_device(dL, dR, dD, st)
+    torch.cuda.synchronize()
+got = dD.cpu().numpy()
+m.close()
+for i in range(n):
+    want = orc.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w)
+    assert np.array_equal(got[i], want), (i, int((got[i] != want).sum()))
+print("ok")
+''' % ROOT
+    env = dict(os.environ, RTDM_LANES="2", RTDM_PIECES="5")
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-2000:]
