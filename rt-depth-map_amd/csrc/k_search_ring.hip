@@ -15,7 +15,7 @@
 // of a wave -- p + h * 64/LPP, h = 0..LPP-1, each with a slice of D/LPP disparities -- and rows are processed in GROUPS of LPP:
 // the lane with h = k owns row k of the group and produces its output pixel.
 //   LPP = 2 (D <= 48; D = 64 as an A/B form): ring 160 registers at D = 64, w = 9 => two waves per SIMD
-//   LPP = 4 (D = 64): ring 80 registers, 148 VGPRs => three waves (four for w <= 7)
+//   LPP = 4 (D = 64, 96): ring 80 registers at (64, 9), 148 VGPRs => three waves (four for w <= 7; two for D = 96)
 //   LPP = 8 (D = 128): ring 96 registers at w = 11; two waves (the selection records, 17 KB per wave, allow no more)
 // Selection wants all D values of a pixel in one place.  Two forms (rtdm_select.h):
 //   * transposing (LPP = 2, D <= 32): one v_permlane32_swap per register hands the lower lane both halves of row t and the
@@ -96,7 +96,7 @@ struct RingCfg {
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
     // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
-    static constexpr int WAVES = LPP == 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : RING_REGS <= 96 ? 3 : 2) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;
+    static constexpr int WAVES = LPP == 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
@@ -454,10 +454,11 @@ static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g
 
 // Instantiations: (D, blockSize, lanes per pixel).  Two lanes per pixel: every (D, blockSize) whose ring (blockSize+1) * D/4
 // registers per lane leaves room for two waves per SIMD.  Four lanes per pixel: the D = 64 ones, whose two-lane ring holds
-// them at two waves (D = 32 with four lanes measured 0-8 % slower than with two: not instantiated).  Eight lanes: D = 128.
+// them at two waves, and D = 96 (D = 32 with four lanes measured 0-8 % slower than with two: not instantiated).  Eight
+// lanes: D = 128.
 #define RTDM_RING_TABLE(X) X(64, 9, 2) X(64, 7, 2) X(64, 5, 2) X(32, 7, 2) X(32, 9, 2) X(32, 11, 2) X(32, 13, 2) X(48, 7, 2) X(48, 9, 2) \
                            X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4) X(64, 11, 4) X(64, 13, 4) \
-                           X(128, 7, 8) X(128, 9, 8) X(128, 11, 8) X(128, 13, 8)
+                           X(128, 7, 8) X(128, 9, 8) X(128, 11, 8) X(128, 13, 8) X(96, 7, 4) X(96, 9, 4) X(96, 11, 4)
 
 static int g_ring_mode = -1;            // rtdm_debug_search_kernel: 0 never, 1 wherever instantiated, -1 default;
 static int g_ring_lpp = 0;              //   2 / 4: wherever instantiated, with that many lanes per pixel where that form exists

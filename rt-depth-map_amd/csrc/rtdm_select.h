@@ -320,7 +320,7 @@ __device__ __forceinline__ void xr_bcast(uint32_t t, uint32_t (&out)[LPP])
 template <int D, int LPP>
 struct GroupSelect {
     static constexpr int NRL = D / (2 * LPP), NGH = NRL / 4;
-    static_assert(D == 16 || D == 32 || D == 48 || D == 64 || D == 128, "record stride checked for these sizes only");
+    static_assert(D == 16 || D == 32 || D == 48 || D == 64 || D == 96 || D == 128, "record stride checked for these sizes only");
     static_assert(NRL % 4 == 0, "a lane's slice must be whole groups of eight disparities");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
     uint32_t mm[LPP][NGH];      // minimum of each group of this lane's slice, per row
