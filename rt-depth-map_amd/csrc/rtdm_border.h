@@ -33,11 +33,9 @@ __device__ __forceinline__ int border_div_trunc(int num, int den)   // den > 0, 
 {                                                                    // 30-instruction integer division sequence
     const unsigned an = (unsigned)(num < 0 ? -num : num);
     unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
-    int rem = (int)an - (int)(q * (unsigned)den);
-    if (rem < 0) { --q; rem += den; }
-    if (rem < 0) { --q; rem += den; }
-    if (rem >= den) { ++q; rem -= den; }
-    if (rem >= den) { ++q; }
+    const int rem = (int)an - (int)(q * (unsigned)den);          // |quotient| <= 128 here: the estimate is within one
+    if (rem < 0) --q;
+    else if (rem >= den) ++q;
     return num < 0 ? -(int)q : (int)q;
 }
 
@@ -115,8 +113,14 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
     const int nsteps = (ys1 - ys0) + w - 1;
     int slot = 0;
     int16_t* db = disp.base + (size_t)f * disp.frame_e;
+    const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
+    // What follows the wave-wide reductions of a row -- tests on three numbers, the sub-pixel division, the stores -- is
+    // scalar work: done per row it would occupy the VALU with one live lane.  The rows of a batch leave their numbers in
+    // lane k of five registers (v_writelane) and the lanes finish the batch's rows side by side.
+    int rec_m1 = 0, rec_a = 0, rec_pp = 0, rec_nn = 0, rec_yf = 0;
     for (int s0 = 0; s0 < nsteps; s0 += RB) {
         const int nb = min(RB, nsteps - s0);
+        int nrec = 0;
         for (int b = 0; b < nb; ++b) {
             const int row = ys0 - r + s0 + b;
             const uint32_t* rrow = (const uint32_t*)(Rb + (size_t)row * Rp.pitch + ra);    // plane pitches are multiples of 64
@@ -175,7 +179,7 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
             const int m1 = (int)(k >> 8), a = (int)(k & 0xffu);
             bool fail = tsum < g.tex;
             if (g.uniq > 0) {
-                const int thresh = m1 + (g.uniq < 512 ? border_div_trunc(m1 * g.uniq, 100) : m1 * g.uniq / 100);
+                const int thresh = m1 + (int)((unsigned)(m1 * g.uniq) / 100u);     // wave-uniform: scalar ALU
                 bool hit = false;
 #pragma unroll
                 for (int c = 0; c < NCH; ++c) {
@@ -192,17 +196,24 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
                 if ((ip >> 6) == c) pp = __builtin_amdgcn_readlane(S[c], ip & 63);
                 if ((in >> 6) == c) nn = __builtin_amdgcn_readlane(S[c], in & 63);
             }
-            if (lane == 0) {
-                int out = g.filtered;
-                if (!fail) {
-                    const int den = pp + nn - 2 * m1 + abs(pp - nn);
-                    const int v = (D - a - 1 + g.minD) * 256 + (den != 0 ? border_div_trunc((pp - nn) * 256, den) : 0) + 15;
-                    out = v >> 4;
-                    if (g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)m1;
-                }
-                if (g.mask_cols && (col < g.vx0 || col >= g.vx1)) out = g.filtered;
-                db[(size_t)y * disp.pitch_e + col] = (int16_t)out;
+            rec_m1 = __builtin_amdgcn_writelane(m1, nrec, rec_m1);
+            rec_a = __builtin_amdgcn_writelane(a, nrec, rec_a);
+            rec_pp = __builtin_amdgcn_writelane(pp, nrec, rec_pp);
+            rec_nn = __builtin_amdgcn_writelane(nn, nrec, rec_nn);
+            rec_yf = __builtin_amdgcn_writelane(y * 2 + (fail ? 1 : 0), nrec, rec_yf);
+            ++nrec;
+        }
+        if (lane < nrec) {
+            const int y = rec_yf >> 1;
+            int out = g.filtered;
+            if (!(rec_yf & 1)) {
+                const int den = rec_pp + rec_nn - 2 * rec_m1 + abs(rec_pp - rec_nn);
+                const int v = (D - rec_a - 1 + g.minD) * 256 + (den != 0 ? border_div_trunc((rec_pp - rec_nn) * 256, den) : 0) + 15;
+                out = v >> 4;
+                if (g.want_cost) cost[((size_t)f * g.H + y) * g.Ws + col] = (uint16_t)rec_m1;
             }
+            if (masked_col) out = g.filtered;
+            db[(size_t)y * disp.pitch_e + col] = (int16_t)out;
         }
         __builtin_amdgcn_wave_barrier();
     }
