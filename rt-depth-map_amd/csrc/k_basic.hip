@@ -319,9 +319,8 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = g.W, INV = g.filtered;
     const int Wp = (W + 7) & ~7;                                      // LDS rows hold whole 8-column chunks
-    uint32_t* key = (uint32_t*)smem;                                  // Wp keys: cost << 16 | x, + the spare slot key[Wp]
-    int16_t* snap = (int16_t*)(key + Wp + 4);                         // Wp: the row before the check
-    int16_t* fin = snap + Wp;                                         // Wp: the row after it (SPK)
+    uint32_t* key = (uint32_t*)smem;                                  // Wp keys: cost << 16 | (d + 0x8000); key[W] stays "none", key[W+1] takes the votes nobody uses
+    int16_t* fin = (int16_t*)(key + Wp + 4);                          // Wp: the row after the check (SPK)
     __shared__ int wsum[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int x0 = tid * 8;
@@ -346,15 +345,17 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
             if (!((inimg >> k) & 1)) d8.v[k] = (int16_t)INV;          // ragged last chunk: padding columns do not exist
             im |= (unsigned)(d8.v[k] != INV) << k;
         }
-        *(Short8*)(snap + x0) = d8;
         const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
         ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
     }
-    if (tid == 0) key[Wp] = ~0u;
+    if (tid == 0) { key[Wp] = ~0u; key[Wp + 1] = ~0u; }              // (W == Wp: the two extra slots lie behind the chunks)
     __syncthreads();
-    // Votes and look-ups are straight-line code for all eight columns: a column that may not vote (or whose target lies
-    // outside the row) votes into the spare slot key[Wp], a look-up outside the row reads that slot too (it holds a vote
-    // nobody uses, or ~0).  Per-column branches cost more in exec-mask bookkeeping than the work they skip.
+    // Votes and look-ups are straight-line code for all eight columns (per-column branches cost more in exec-mask
+    // bookkeeping than the work they skip).  The key of a vote carries the voter's DISPARITY, not its column: among the
+    // voters of one right column a smaller x means a smaller disparity (x - x2 is its rounded integer part), so the
+    // minimum still prefers the lower cost and then the first voter, and a look-up has the winner's disparity without a
+    // second read.  A column that may not vote, or whose target lies outside the row, votes into key[W+1]; a look-up
+    // outside the row reads key[W], which nobody writes: "no vote".
     if (active) {
         const unsigned vm = im & votem;
 #pragma unroll
@@ -362,37 +363,35 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
             const int x = x0 + k, d = d8.v[k];
             const int x2 = x - ((d + 8) >> 4);
             const bool ok = ((vm >> k) & 1) && (unsigned)x2 < (unsigned)W;
-            atomicMin(&key[ok ? x2 : Wp], ((uint32_t)(uint16_t)c8.v[k] << 16) | (uint32_t)x);
+            atomicMin(&key[ok ? x2 : W + 1], ((uint32_t)(uint16_t)c8.v[k] << 16) | ((uint32_t)(d + 0x8000) & 0xffffu));
         }
     }
     __syncthreads();
     if (active) {
         const unsigned chk = im & votem & keepm;                      // columns whose two matches are looked up
         unsigned kill = im & ~keepm;                                  // outside the valid rectangle: always dropped
+        // |d2 - d| > M  <=>  (unsigned)(d2 - d + M) > 2 M; unchecked columns are masked once, at the end
+        const unsigned M2 = 2u * (unsigned)maxDiff16;
+        const int dofs = maxDiff16 - 0x8000;
         unsigned bad0m = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int x = x0 + k, d = d8.v[k];
-            const int xa = x - (d >> 4);
-            const bool in = ((chk >> k) & 1) && (unsigned)xa < (unsigned)W;
-            const uint32_t q = key[in ? xa : Wp];
-            int dv = snap[min(q & 0xffffu, (uint32_t)(Wp - 1))];
-            asm volatile("" : "+v"(dv));                              // keep the read unconditional (no branch around it)
-            bad0m |= ((unsigned)in & (unsigned)(q != ~0u) & (unsigned)(abs(dv - d) > maxDiff16)) << k;
+            const uint32_t q = key[min((unsigned)(x - (d >> 4)), (unsigned)W)];
+            bad0m |= ((unsigned)(q != ~0u) & (unsigned)((unsigned)((int)(q & 0xffffu) - d + dofs) > M2)) << k;
         }
+        bad0m &= chk;
         // a pixel dies only if BOTH matches disagree: the second look-ups are needed only where the first ones did
         // (consistent regions: by none of the wave's lanes)
         if (__builtin_amdgcn_ballot_w64(bad0m != 0) != 0) {
+            unsigned bad1m = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int x = x0 + k, d = d8.v[k];
-                const int xb = x - ((d + 15) >> 4);
-                const bool in = ((bad0m >> k) & 1) && (unsigned)xb < (unsigned)W;
-                const uint32_t q = key[in ? xb : Wp];
-                int dv = snap[min(q & 0xffffu, (uint32_t)(Wp - 1))];
-                asm volatile("" : "+v"(dv));
-                kill |= ((unsigned)in & (unsigned)(q != ~0u) & (unsigned)(abs(dv - d) > maxDiff16)) << k;
+                const uint32_t q = key[min((unsigned)(x - ((d + 15) >> 4)), (unsigned)W)];
+                bad1m |= ((unsigned)(q != ~0u) & (unsigned)((unsigned)((int)(q & 0xffffu) - d + dofs) > M2)) << k;
             }
+            kill |= bad0m & bad1m;
         }
         if (kill) {
 #pragma unroll
@@ -472,7 +471,7 @@ bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
                      (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2) | (size_t)cost | (size_t)headmap) & 15) == 0;
     if (vec) {
         const dim3 vblock((unsigned)(((Wp >> 3) + 63) & ~63));
-        const size_t lds = (size_t)Wp * 8 + 16;
+        const size_t lds = (size_t)Wp * 6 + 16;
         if (label) hipLaunchKernelGGL(k_lrcheck_vec<true>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
         else       hipLaunchKernelGGL(k_lrcheck_vec<false>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
         return label != nullptr;
