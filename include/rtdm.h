@@ -40,7 +40,7 @@ typedef enum rtdm_status {
 typedef struct rtdm_bm_params {
     int preFilterCap;      /* 1..63 */
     int blockSize;         /* odd, 5..255, smaller than min(width,height) */
-    int minDisparity;
+    int minDisparity;      /* >= -2047 and minDisparity + numDisparities <= 2047: the x16 output is 16 bits wide */
     int numDisparities;    /* > 0, multiple of 16 */
     int textureThreshold;  /* >= 0 */
     int uniquenessRatio;   /* >= 0 */

@@ -130,6 +130,8 @@ static int validate_params(const rtdm_bm_params& p)
     if (p.blockSize < 5 || p.blockSize > 255 || (p.blockSize & 1) == 0) return RTDM_ERR_BAD_PARAM;
     if (p.numDisparities <= 0 || p.numDisparities % 16 != 0) return RTDM_ERR_BAD_PARAM;
     if (p.textureThreshold < 0 || p.uniquenessRatio < 0) return RTDM_ERR_BAD_PARAM;
+    // the x16 fixed-point output is 16 bits wide: (minDisparity - 1) * 16 .. (minDisparity + numDisparities) * 16 must fit
+    if (p.minDisparity < -2047 || (long)p.minDisparity + p.numDisparities > 2047) return RTDM_ERR_BAD_PARAM;
     return RTDM_OK;
 }
 

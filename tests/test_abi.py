@@ -43,7 +43,8 @@ def test_parameter_validation_precedes_device_use():
     L = B.lib()
     h = C.c_void_p()
     for bad in (dict(numDisparities=20), dict(blockSize=8), dict(blockSize=3), dict(preFilterCap=0),
-                dict(preFilterCap=64), dict(textureThreshold=-1), dict(uniquenessRatio=-1)):
+                dict(preFilterCap=64), dict(textureThreshold=-1), dict(uniquenessRatio=-1), dict(minDisparity=-2048),
+                dict(minDisparity=2000, numDisparities=64)):
         p = B.make_params(**bad)
         assert L.rtdm_bm_create(C.byref(p), 64, 48, 1, 0, C.byref(h)) == -1, bad
     assert L.rtdm_bm_create(None, 64, 48, 1, 0, C.byref(h)) == -7
