@@ -116,7 +116,7 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
     const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
     // What follows the wave-wide reductions of a row -- tests on three numbers, the sub-pixel division, the stores -- is
     // scalar work: done per row it would occupy the VALU with one live lane.  The rows of a batch leave their numbers in
-    // lane k of five registers (v_writelane) and the lanes finish the batch's rows side by side.
+    // lane k of five registers and the lanes finish the batch's rows side by side.
     int rec_m1 = 0, rec_a = 0, rec_pp = 0, rec_nn = 0, rec_yf = 0;
     for (int s0 = 0; s0 < nsteps; s0 += RB) {
         const int nb = min(RB, nsteps - s0);
@@ -196,11 +196,9 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
                 if ((ip >> 6) == c) pp = __builtin_amdgcn_readlane(S[c], ip & 63);
                 if ((in >> 6) == c) nn = __builtin_amdgcn_readlane(S[c], in & 63);
             }
-            rec_m1 = __builtin_amdgcn_writelane(m1, nrec, rec_m1);
-            rec_a = __builtin_amdgcn_writelane(a, nrec, rec_a);
-            rec_pp = __builtin_amdgcn_writelane(pp, nrec, rec_pp);
-            rec_nn = __builtin_amdgcn_writelane(nn, nrec, rec_nn);
-            rec_yf = __builtin_amdgcn_writelane(y * 2 + (fail ? 1 : 0), nrec, rec_yf);
+            const bool me = lane == nrec;                               // (one compare, five selects with scalar sources)
+            rec_m1 = me ? m1 : rec_m1; rec_a = me ? a : rec_a; rec_pp = me ? pp : rec_pp; rec_nn = me ? nn : rec_nn;
+            rec_yf = me ? y * 2 + (fail ? 1 : 0) : rec_yf;
             ++nrec;
         }
         if (lane < nrec) {
