@@ -284,6 +284,28 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         parity_ok = int(flag.item()) == 0
 
+    # "ms/frame" for a caller that hands over ONE frame at a time (the reference's loop, estimator.cpp:56): host to host
+    # through rtdm_bm_compute -- pageable frames in, pageable map out, PCIe inclusive -- and the device-resident call alone.
+    # Outside the timed region; reported beside the throughput figure, never instead of it.
+    single = None
+    if rank == 0 and world == 1:
+        L1, R1 = dL[0].cpu().numpy(), dR[0].cpu().numpy()
+        out1 = np.empty((H, W), np.int16)
+        m1 = pkg.HIPMatcher(numOfDisparities=D, blockSize=BLOCK, width=W, height=H, max_batch=1, device=local_rank)
+        for _ in range(5): m1.compute(L1, R1, out1)
+        t1 = time.perf_counter()
+        for _ in range(50): m1.compute(L1, R1, out1)
+        h2h = (time.perf_counter() - t1) / 50
+        for _ in range(5): m1.compute_device(dL[:1], dR[:1], dD[:1], stream)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            m1.compute_device(dL[:1], dR[:1], dD[:1], stream); torch.cuda.synchronize()
+        dev1 = (time.perf_counter() - t1) / 50
+        single = {"host_to_host_ms": round(h2h * 1e3, 4), "device_resident_ms": round(dev1 * 1e3, 4),
+                  "same_as_batched": bool(np.array_equal(out1, want[0])),
+                  "note": "one 1280x720 pair per call; host_to_host = rtdm_bm_compute (pageable in/out, PCIe inclusive)"}
+        m1.close()
     valid_frac = float((dD != m.filtered).float().mean().item())
     total_pairs = world * B * args.steps
     value = total_pairs / elapsed
@@ -337,6 +359,7 @@ def main():
                      "algorithmic_bytes_per_pair": ALGO_BYTES_PER_PAIR},
         "stage_ms_per_launch": {k: round(v["total_ms"] / max(1, v["launches"]), 4) for k, v in stages.items()},
         "compute_view": compute_view,
+        "single_frame": single,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pkg)
