@@ -482,16 +482,40 @@ int ring_lanes_per_pixel(const BMGeom& g) { return ring_lpp(g); }
 
 static int ring_tile(const BMGeom& g) { return 256 / ring_lpp(g); }
 
+// workgroups resident per CU (= waves per SIMD: a workgroup is four waves, one per SIMD) of the form (D, w) runs
+static int ring_wgs_per_cu(const BMGeom& g)
+{
+    const int lpp = ring_lpp(g);
+#define X(DD, WW, LL) if (g.D == DD && g.w == WW && lpp == LL) return RingCfg<DD, WW, LL>::WAVES;
+    RTDM_RING_TABLE(X)
+#undef X
+    return 2;
+}
+
 int ring_strips_model(const BMGeom& g, int n)
 {
     int x0 = 0, nx = 0;
     if (!ring_range(g, &x0, &nx) || !ring_lpp(g)) return 1;
     const int tile = ring_tile(g), tiles = (nx + tile - 1) / tile, nrows = g.vy1 - g.vy0;
-    // 2 (3) workgroups per CU resident => 512 (768) slots; a strip pays w-1 filling rows at about half the price of an output row
-    const float slots = tile == 64 ? 768.0f : 512.0f;
-    int s = (int)(sqrtf((float)nrows * slots / (0.5f * (float)(g.w - 1) * (float)tiles * (float)n)) + 0.5f);
-    s = max(s, (nrows + ring_rows_cap(g) - 1) / ring_rows_cap(g));
-    return max(1, min(s, (nrows + 15) / 16));
+    const int slots = 256 * ring_wgs_per_cu(g);             // workgroups in flight on the chip
+    const int smin = max(1, (nrows + ring_rows_cap(g) - 1) / ring_rows_cap(g)), smax = max(smin, (nrows + 15) / 16);
+    // a strip pays w-1 filling rows at about half the price of an output row
+    const float fill = 0.5f * (float)(g.w - 1);
+    int s = (int)(sqrtf((float)nrows * (float)slots / (fill * (float)tiles * (float)n)) + 0.5f);
+    s = max(smin, min(s, smax));
+    if ((long)tiles * s * n < 6L * slots) {
+        // Small jobs (single frames, small batches -- nothing measures their strip count): the grid is a handful of
+        // scheduling rounds, and a round that is started is paid in full.  Time ~ rounds x (rows per workgroup + fill + a
+        // fixed two rows' worth of prologue); take the strip count that minimises it.
+        float best = 1e30f;
+        for (int c = smin; c <= smax; ++c) {
+            const int rs = (nrows + c - 1) / c, ce = (nrows + rs - 1) / rs;
+            const long rounds = ((long)tiles * ce * n + slots - 1) / slots;
+            const float t = (float)rounds * ((float)rs + fill + 2.0f);
+            if (t < best) { best = t; s = ce; }
+        }
+    }
+    return s;
 }
 
 template <int D, int WS, int LPP>
