@@ -35,6 +35,7 @@
 // v_qsad/v_mqsad_pk_u16_u8 16.4; v_add/sub/and/xor/mov 2.6; everything else used here (packed u16 ops, v_perm,
 // v_cndmask, v_min3, v_cmp, shifts, v_sad_u8) 4.2-4.7; v_permlane32_swap 8.1.
 #include "rtdm_select.h"
+#include "rtdm_border.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -73,6 +74,8 @@ struct RingGeom {
     int tiles, strips;   // column tiles x row strips per frame
     unsigned nitems;     // workgroups over the whole batch
     unsigned chunk;      // ceil(nitems / 8): consecutive items one XCD works through (0: no remapping)
+    unsigned nborder;    // border-column workgroups in FRONT of the tile workgroups (single frames and small batches, where a
+    int bgx, bgy;        // second launch or a side stream costs more than it hides; rtdm_border.h); 0: none
 };
 
 // LPP = lanes per pixel: the D disparities of a pixel are split over LPP lanes of a wave (p + h * 64/LPP, h = 0..LPP-1), and
@@ -98,6 +101,9 @@ struct RingCfg {
     // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
     static constexpr int WAVES = LPP == 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : RING_REGS <= 72 ? 4 : RING_REGS <= 112 ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
+    // border-column workgroups may ride in this kernel's grid (small launches); not in the four-wave forms, whose 128
+    // registers the border body's code would overflow
+    static constexpr bool FUSE_BORDER = WAVES < 4;
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
     static constexpr bool ROW_PTRS = !(LPP == 2 && RING_REGS > 88 && RING_REGS <= 112);
@@ -193,8 +199,11 @@ template <typename F, int... R>
 __device__ __forceinline__ void ring_for_rows(std::integer_sequence<int, R...>, F&& f)
 { (f(std::integral_constant<int, R>{}), ...); }
 
-template <int D, int WS, int LPP>
-__global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg)
+// FUSE: the grid starts with rg.nborder border-column workgroups (an instantiation of its own: with the border body inside,
+// the tile loop of the batch form came out 1.6 % slower)
+template <int D, int WS, int LPP, bool FUSE>
+__global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg,
+                                                                                   BorderGeom bg)
 {
     using C = RingCfg<D, WS, LPP>;
     constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS, PPW = C::PPW;
@@ -207,6 +216,15 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     // XCD k takes the items [k chunk, (k+1) chunk) in order, so the tiles of a strip -- which share their D + w column halo
     // -- and the strips of a frame -- which share w-1 rows -- meet in ONE L2 instead of being fetched into eight.
     unsigned fi = blockIdx.x;
+    if constexpr (FUSE) {
+        if (fi < rg.nborder) {
+            // border columns: a latency-bound walk, dispatched first so that it runs under the tiles
+            const unsigned per = (unsigned)(rg.bgx * rg.bgy), fr = fi / per, id = fi - fr * per;
+            border_body<(D + 63) / 64>((unsigned char*)lds, Lp, Rp, disp, cost, g, bg, (int)(id % rg.bgx), (int)(id / rg.bgx), (int)fr);
+            return;
+        }
+        fi -= rg.nborder;
+    }
     if (rg.chunk) fi = (fi & 7u) * rg.chunk + (fi >> 3);
     if (fi >= rg.nitems) return;
     const int b_tile = (int)(fi % rg.tiles), b_strip = (int)((fi / rg.tiles) % rg.strips), f = (int)(fi / (rg.tiles * rg.strips));
@@ -519,7 +537,8 @@ int ring_strips_model(const BMGeom& g, int n)
 }
 
 template <int D, int WS, int LPP>
-static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint)
+static bool ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint,
+                            bool fuse_border)
 {
     using C = RingCfg<D, WS, LPP>;
     RingGeom rg;
@@ -539,18 +558,34 @@ static void ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
     static const bool xcd_local = [] { const char* e = getenv("RTDM_RING_XCD"); return !e || atoi(e) != 0; }();   // A/B switch
     rg.chunk = xcd_local ? (rg.nitems + 7) / 8 : 0;
     const unsigned grid = rg.chunk ? rg.chunk * 8 : rg.nitems;
-    static const size_t ldspad = [] { const char* e = getenv("RTDM_RING_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
-    const size_t ldsb = (size_t)4 * C::WAVE_LDS * sizeof(uint32_t) + ldspad;   // (padding: occupancy experiments)
-    if (ldsb > 48 * 1024) {                         // once per device of this process (a handle lives on one device)
-        static unsigned long long done = 0;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (dev >= 64 || !((done >> dev) & 1)) {
-            (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS, LPP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-            if (dev < 64) done |= 1ull << dev;
-        }
+    BorderGeom bg{};
+    size_t blds = 0;
+    rg.nborder = 0; rg.bgx = rg.bgy = 0;
+    if (fuse_border && C::FUSE_BORDER) {
+        int lx0, lx1, rx0, rx1;
+        fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
+        if (border_geometry(g, lx0, lx1, rx0, rx1, n, &bg, &rg.bgx, &rg.bgy, &blds)) rg.nborder = (unsigned)(rg.bgx * rg.bgy) * (unsigned)n;
     }
-    hipLaunchKernelGGL((k_search_ring<D, WS, LPP>), dim3(grid), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg);
+    static const size_t ldspad = [] { const char* e = getenv("RTDM_RING_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+    const size_t ldsb = max((size_t)4 * C::WAVE_LDS * sizeof(uint32_t), blds) + ldspad;   // (padding: occupancy experiments)
+    const auto launch = [&](auto Fc) {
+        constexpr bool F = decltype(Fc)::value;
+        if (ldsb > 48 * 1024) {                     // once per device of this process (a handle lives on one device)
+            static unsigned long long done = 0;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev >= 64 || !((done >> dev) & 1)) {
+                (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS, LPP, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max(ldsb, (size_t)64 * 1024));
+                if (dev < 64) done |= 1ull << dev;
+            }
+        }
+        hipLaunchKernelGGL((k_search_ring<D, WS, LPP, F>), dim3(grid + rg.nborder), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg, bg);
+    };
+    if constexpr (C::FUSE_BORDER) {
+        if (rg.nborder) { launch(std::true_type{}); return true; }
+    }
+    launch(std::false_type{});
+    return false;
 }
 
 bool ring_search_supported(const BMGeom& g)
@@ -565,12 +600,14 @@ bool ring_search_supported(const BMGeom& g)
     return ring_lpp(g) != 0;
 }
 
-void launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint)
+bool launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream, int strips_hint,
+                        bool fuse_border)
 {
     const int lpp = ring_lpp(g);
-#define X(DD, WW, LL) if (g.D == DD && g.w == WW && lpp == LL) { ring_launch_one<DD, WW, LL>(Lp, Rp, disp, cost, g, n, stream, strips_hint); return; }
+#define X(DD, WW, LL) if (g.D == DD && g.w == WW && lpp == LL) return ring_launch_one<DD, WW, LL>(Lp, Rp, disp, cost, g, n, stream, strips_hint, fuse_border);
     RTDM_RING_TABLE(X)
 #undef X
+    return false;
 }
 
 }  // namespace rtdm

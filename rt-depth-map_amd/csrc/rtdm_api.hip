@@ -325,7 +325,7 @@ static int chunk_back(rtdm_bm* bm, const Lane& ln, int n, int W, int H, Plane16W
 static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plane16W disp, const BMGeom& g, int n, hipStream_t s, bool fuse, bool ring)
 {
     const auto launch = [&](int c) {
-        if (ring) launch_search_ring(Lpr, Rpr, disp, ln.dCost, g, n, s, c);
+        if (ring) launch_search_ring(Lpr, Rpr, disp, ln.dCost, g, n, s, c, fuse);
         else launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);
     };
     static int enabled = -1;
@@ -445,7 +445,7 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
             // (search -2 %).  Single frames keep the fused launch (one kernel less).  RTDM_BORDER_ASYNC=0: always fused.
             static const bool async_border = [] { const char* e = getenv("RTDM_BORDER_ASYNC"); return !e || atoi(e) != 0; }();
             const bool side = async_border && border_search_supported(g) && n >= 16;
-            const bool fuse = border_search_supported(g) && !separate && !side && !ring;   // the ring kernel's grid has tiles only
+            const bool fuse = border_search_supported(g) && !separate && !side;   // border workgroups inside the tile kernel's grid
             // (measured, if at all, before the side stream forks: nothing else runs beside the timed launches)
             const int strips = tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse, ring);
             if (side) {
@@ -454,11 +454,12 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, ln.side, lx0, lx1, rx0, rx1);
                 HIPC(hipEventRecord(ln.join, ln.side));
             }
-            if (ring) launch_search_ring(Lpr, Rpr, disp, ln.dCost, g, n, s, strips);
+            bool fused = fuse;
+            if (ring) fused = launch_search_ring(Lpr, Rpr, disp, ln.dCost, g, n, s, strips, fuse);
             else launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, strips);
             if (side) {
                 HIPC(hipStreamWaitEvent(s, ln.join, 0));
-            } else if (fuse) {
+            } else if (fused) {
             } else if (border_search_supported(g)) {
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, s, lx0, lx1, rx0, rx1);
             } else {

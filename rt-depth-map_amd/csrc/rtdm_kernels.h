@@ -55,11 +55,12 @@ void launch_search_fast(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const B
                         int n, hipStream_t stream, bool fuse_border, int strips_hint = 0);
 int fast_strips_model(const BMGeom& g, int n);
 // K2 (ring variant, k_search_ring.hip): the same columns as the fast variant, prefix sums in a register ring instead of a
-// leaving-row recomputation; covers the (D, blockSize) pairs whose ring fits two waves per SIMD.  Border columns always go
-// to launch_search_border.  ring_search_supported implies fast_search_supported's column range.
+// leaving-row recomputation; covers the (D, blockSize) pairs whose ring fits two waves per SIMD.  fuse_border: the border
+// columns may ride in front of the tile workgroups of the same launch; returns whether they did (otherwise they go to
+// launch_search_border).  ring_search_supported implies fast_search_supported's column range.
 bool ring_search_supported(const BMGeom& g);
-void launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream,
-                        int strips_hint = 0);
+bool launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n, hipStream_t stream,
+                        int strips_hint = 0, bool fuse_border = false);
 int ring_strips_model(const BMGeom& g, int n);
 void ring_set_mode(int mode);   // rtdm_debug_search_kernel
 int ring_lanes_per_pixel(const BMGeom& g);   // 2 / 4: the form of k_search_ring this configuration runs (0: none)
