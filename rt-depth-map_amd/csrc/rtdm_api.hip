@@ -417,10 +417,8 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
     *anyout = any;
     if (!any) { launch_fill16(disp, 0, W, 0, H, n, g.filtered, s); return RTDM_OK; }
     // the search kernels write columns [cx0, cx1) of the valid rows; everything else is FILTERED
-    launch_fill16(disp, 0, W, 0, g.vy0, n, g.filtered, s);
-    launch_fill16(disp, 0, W, g.vy1, H, n, g.filtered, s);
-    launch_fill16(disp, 0, g.cx0, g.vy0, g.vy1, n, g.filtered, s);
-    launch_fill16(disp, g.cx1, W, g.vy0, g.vy1, n, g.filtered, s);
+    launch_fill_frame(disp, W, H, g.cx0, g.cx1, g.vy0, g.vy1, n, g.filtered,
+                      (p.speckleRange >= 0 && p.speckleWindowSize > 0) ? ln.dRowCnt : nullptr, s);   // (+ the speckle filter's run counts = 0)
     StageEvent ev;
     const bool fast = fast_search_supported(g);
     bool u16 = false;
@@ -482,7 +480,6 @@ static int chunk_back(rtdm_bm* bm, const Lane& ln, int n, int W, int H, Plane16W
     StageEvent ev;
     const bool speckle = p.speckleRange >= 0 && p.speckleWindowSize > 0;
     const bool lr = p.disp12MaxDiff >= 0;
-    if (speckle) HIPC(hipMemsetAsync(ln.dRowCnt, 0, (size_t)n * H * sizeof(int32_t), s));
     bool compact_heads = false;
     if (lr) {
         stage_begin(bm, RTDM_STAGE_LRCHECK, n, s, &ev);

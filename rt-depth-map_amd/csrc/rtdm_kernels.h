@@ -37,6 +37,9 @@ void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, 
 
 // Fill the rectangle [x0,x1) x [y0,y1) of every disparity frame with `value`.
 void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int value, hipStream_t stream);
+// The complement of [cx0, cx1) x [vy0, vy1) in every frame, plus (rowcnt != null) rowcnt[n][H] = 0, in one launch.
+void launch_fill_frame(Plane16W disp, int W, int H, int cx0, int cx1, int vy0, int vy1, int n, int value, int32_t* rowcnt,
+                       hipStream_t stream);
 
 // K2 (generic variant): any D <= 256, any odd w, LDS column sums; writes disp (+ int32 cost).
 // Returns false if the configuration does not fit (caller reports RTDM_ERR_UNSUPPORTED).
