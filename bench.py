@@ -199,6 +199,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024,
                     help="pairs per step per GPU (BASELINE config 4's stream length; 256 is 4 percent slower: tail effects of the search grid)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true",
+                    help="skip the single-frame latency measurement (profiling runs: its launches would mix into per-kernel averages)")
     ap.add_argument("--rccl-stream", type=int, default=0, metavar="FRAMES",
                     help="BASELINE config 4 instead of the headline: rank 0 owns FRAMES pairs, scatter -> compute -> gather "
                          "over torch.distributed (RCCL); reports root-sourced pairs/s")
@@ -288,7 +290,7 @@ def main():
     # through rtdm_bm_compute -- pageable frames in, pageable map out, PCIe inclusive -- and the device-resident call alone.
     # Outside the timed region; reported beside the throughput figure, never instead of it.
     single = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_single_frame:
         L1, R1 = dL[0].cpu().numpy(), dR[0].cpu().numpy()
         out1 = np.empty((H, W), np.int16)
         m1 = pkg.HIPMatcher(numOfDisparities=D, blockSize=BLOCK, width=W, height=H, max_batch=1, device=local_rank)

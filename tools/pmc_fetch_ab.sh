@@ -7,7 +7,7 @@ for V in "$@"; do
     export $VAR=$V
     OUT=$R/gpurun_out/pmc_fetch_ab/$VAR-$V
     rm -rf $OUT; mkdir -p $OUT
-    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -- python $R/bench.py --steps 2 --warmup 2 --batch 256 --no-cpu-baseline > /dev/null 2>&1
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -- python $R/bench.py --steps 2 --warmup 2 --batch 256 --no-cpu-baseline --no-single-frame > /dev/null 2>&1
     python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(list)

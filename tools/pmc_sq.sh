@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 TAG=${1:-x}; shift
 OUT=$R/gpurun_out/pmc_sq_$TAG
 rm -rf $OUT; mkdir -p $OUT
-B="--steps 2 --warmup 2 --batch 64 --no-cpu-baseline $@"
+B="--steps 2 --warmup 2 --batch 64 --no-cpu-baseline --no-single-frame $@"
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE \
     --output-format csv -d $OUT/sq -- python $R/bench.py $B > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM \

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_traffic
 rm -rf $OUT; mkdir -p $OUT
-B="--steps 2 --warmup 2 --batch 1024 --no-cpu-baseline"    # the bench's own batch; warm-up 2: the second call measures the strip count
+B="--steps 2 --warmup 2 --batch 1024 --no-cpu-baseline --no-single-frame"    # the bench's own batch; warm-up 2: the second call measures the strip count
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/cal_fetch -- $R/tools/ubench_fetch > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/cal_write -- $R/tools/ubench_fetch > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/bench_fetch -- python $R/bench.py $B > /dev/null 2>&1
