@@ -87,7 +87,10 @@ int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint
                            size_t pitch, size_t frame_stride, int width, int height,
                            int16_t* d_disp, size_t disp_pitch, size_t disp_frame_stride,
                            void* hip_stream);
-/* Host variant: contiguous frames in host memory, H2D / compute / D2H overlapped in chunks. */
+/* Host variant: frames in host memory, processed in chunks; returns when `disp` is complete.  If left, right and disp are
+ * page-locked (hipHostMalloc / hipHostRegister) the copies are DMA on streams of their own: chunk k+1 comes in and chunk
+ * k-1 goes out while chunk k is computed (needs max_batch >= 2).  Pageable memory is staged by the HIP runtime, chunk by
+ * chunk. */
 int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t* right,
                           size_t pitch, size_t frame_stride, int width, int height,
                           int16_t* disp, size_t disp_pitch, size_t disp_frame_stride);

@@ -75,11 +75,13 @@ class HIPMatcher:
             disp.ctypes.data if want_disp else None, W * 2), "rtdm_bm_compute_depth")
         return (mean, cnt, disp) if want_disp else (mean, cnt)
 
-    def compute_batch(self, left, right):
-        """left/right: uint8 [n, H, W] C-contiguous host arrays -> int16 [n, H, W]."""
+    def compute_batch(self, left, right, out=None):
+        """left/right: uint8 [n, H, W] C-contiguous host arrays -> int16 [n, H, W] (out: a C-contiguous int16 [n, H, W]
+        array to write into).  Page-locked arrays (hipHostMalloc / torch pin_memory) move by DMA beside the compute."""
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
         n, H, W = left.shape
-        disp = np.empty((n, H, W), np.int16)
+        disp = np.empty((n, H, W), np.int16) if out is None else out
+        assert disp.dtype == np.int16 and disp.shape == (n, H, W) and disp.flags.c_contiguous
         B.check(B.lib().rtdm_bm_compute_batch(self._h, n, left.ctypes.data, right.ctypes.data, W, W * H, W, H,
                                               disp.ctypes.data, W * 2, W * H * 2), "rtdm_bm_compute_batch")
         return disp

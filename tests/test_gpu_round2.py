@@ -147,3 +147,20 @@ print("ok")
     env = dict(os.environ, RTDM_LANES="2", RTDM_PIECES="5")
     p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, env=env)
     assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-2000:]
+
+
+# ---- rtdm_bm_compute_batch on page-locked host memory: three streams, two halves of the staging planes ------------------
+@pytest.mark.parametrize("W,H,n,mb", [(333, 120, 11, 6), (640, 96, 9, 4), (400, 150, 5, 2), (200, 64, 3, 1)])
+def test_host_batch_pipeline_on_page_locked_memory(pkg, oracle, synth, W, H, n, mb):
+    import torch
+    D, w = 32, 7
+    Ls, Rs = synth.make_stream(77, n, W, H, D)
+    pl, pr = torch.from_numpy(Ls).pin_memory(), torch.from_numpy(Rs).pin_memory()
+    po = torch.full((n, H, W), 12345, dtype=torch.int16).pin_memory()
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=mb)
+    got = m.compute_batch(pl.numpy(), pr.numpy(), po.numpy())
+    again = m.compute_batch(Ls, Rs)                       # the same frames from pageable memory: the unpipelined path
+    m.close()
+    assert np.array_equal(got, again)
+    for i in range(n):
+        assert_same(got[i], oracle.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w))
