@@ -69,7 +69,9 @@ void rtdm_bm_default_params(rtdm_bm_params* p, int numDisparities);
  * rtdm_bm_compute  <- SWMatcherKonolige::compute (bm-sw.cpp:33-38): host 8UC1 left/right with
  *                     arbitrary row pitch (the caller passes ROI views, estimator.cpp:33,36),
  *                     host 16SC1 output, fixed point x16, invalid = (minDisparity-1)*16.
- *                     Synchronous.
+ *                     Synchronous.  Pageable planes are gathered through a page-locked staging area;
+ *                     planes that are themselves page-locked (hipHostMalloc, hipHostRegister) are
+ *                     read and written by DMA in place.
  */
 int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, int max_batch,
                    int device, rtdm_bm** out);

@@ -515,6 +515,14 @@ static int chunk_back(rtdm_bm* bm, const Lane& ln, int n, int W, int H, Plane16W
     return RTDM_OK;
 }
 
+// host memory the GPU can DMA from / to directly (hipHostMalloc, hipHostRegister)?
+static bool page_locked(const void* q)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc memory: an error, not a fault
+    return a.type == hipMemoryTypeHost;
+}
+
 static int check_frame(const rtdm_bm* bm, int W, int H)
 {
     if (W <= 0 || H <= 0 || W > bm->maxW || H > bm->maxH) return RTDM_ERR_BAD_SIZE;
@@ -597,11 +605,6 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
     // pageable 11.2 k -> 10.5 k: so only for page-locked callers.  RTDM_BATCH_PIPELINE = 0 never, 2 always.
     const int half = std::max(1, bm->laneB / 2);
     static const int pipe_mode = [] { const char* e = getenv("RTDM_BATCH_PIPELINE"); return e ? atoi(e) : 1; }();
-    const auto page_locked = [](const void* q) {
-        hipPointerAttribute_t a;
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }   // plain malloc memory: an error, not a fault
-        return a.type == hipMemoryTypeHost;
-    };
     const bool two = bm->laneB >= 2 && (pipe_mode == 2 || (pipe_mode == 1 && page_locked(left) && page_locked(right) && page_locked(disp)));
     const int chunk = two ? half : bm->laneB;
     int k = 0;
@@ -662,6 +665,19 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
     // 0.363 ms with one copy per plane and row-by-row gathers, 0.347 with one band, 0.325 with two, 0.375 with four (every
     // further async copy costs more in the runtime than its overlap hides; RTDM_HOST_BANDS=1..4).  Rows that are contiguous
     // in the caller's plane move as one memcpy.
+    const size_t Wsd = (size_t)((width + 7) & ~7);
+    if (page_locked(left) && page_locked(right) && page_locked(disp)) {
+        // the caller's planes are page-locked: DMA straight from and to them, no gathers on the host
+        HIPC(hipMemcpy2DAsync(bm->dInL, dpitch, left, left_pitch, (size_t)width, height, hipMemcpyHostToDevice, s));
+        HIPC(hipMemcpy2DAsync(bm->dInR, dpitch, right, right_pitch, (size_t)width, height, hipMemcpyHostToDevice, s));
+        Plane8 Ld{bm->dInL, dpitch, dframe}, Rd{bm->dInR, dpitch, dframe};
+        Plane16W Od{bm->dOut, Wsd, Wsd * (size_t)height};
+        rc = run_chunk(bm, bm->lane[0], 1, Ld, Rd, width, height, Od, s);
+        if (rc) return rc;
+        HIPC(hipMemcpy2DAsync(disp, disp_pitch, bm->dOut, Wsd * sizeof(int16_t), (size_t)width * sizeof(int16_t), height, hipMemcpyDeviceToHost, s));
+        HIPC(hipStreamSynchronize(s));
+        return RTDM_OK;
+    }
     uint8_t* hL = bm->hStage;
     uint8_t* hR = hL + dframe;
     int16_t* hD = (int16_t*)(bm->hStage + 2 * bm->ppitch * (size_t)bm->maxH);

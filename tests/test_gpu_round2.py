@@ -164,3 +164,19 @@ def test_host_batch_pipeline_on_page_locked_memory(pkg, oracle, synth, W, H, n, 
     assert np.array_equal(got, again)
     for i in range(n):
         assert_same(got[i], oracle.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w))
+
+
+# ---- rtdm_bm_compute on page-locked planes: DMA straight from / to the caller's (pitched) views -----------------------
+def test_single_frame_from_page_locked_pitched_views(pkg, oracle, synth):
+    import torch
+    W, H, D, w = 233, 156, 32, 7                                # the reference's crop of a 320-wide frame (estimator.cpp:33,36)
+    Lf, Rf = synth.make_pair(synth.STREAM_SEED + 5, 320, 240, D)
+    pl, pr = torch.from_numpy(Lf).pin_memory(), torch.from_numpy(Rf).pin_memory()
+    po = torch.full((240, 320), 777, dtype=torch.int16).pin_memory()
+    L, R, O = pl.numpy()[40:40 + H, 50:50 + W], pr.numpy()[40:40 + H, 50:50 + W], po.numpy()[40:40 + H, 50:50 + W]
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H)
+    m.compute(L, R, O)
+    m.close()
+    assert_same(O, oracle.bm_compute(np.ascontiguousarray(L), np.ascontiguousarray(R), numDisparities=D, blockSize=w))
+    guard = po.numpy().copy(); guard[40:40 + H, 50:50 + W] = 777
+    assert (guard == 777).all()                                 # nothing outside the view was written
