@@ -112,7 +112,7 @@ def test_every_fast_instantiation(pkg, oracle, synth, D, pieces):
 RING_TABLE = [(64, 9, 2), (64, 7, 2), (64, 5, 2), (32, 7, 2), (32, 9, 2), (32, 11, 2), (32, 13, 2), (48, 7, 2), (48, 9, 2),
               (16, 5, 2), (16, 7, 2), (16, 9, 2), (64, 9, 4), (64, 7, 4), (64, 5, 4), (64, 11, 4), (64, 13, 4),
               (128, 7, 8), (128, 9, 8), (128, 11, 8), (128, 13, 8), (96, 7, 4), (96, 9, 4), (96, 11, 4), (96, 13, 4),
-              (48, 11, 2), (48, 13, 2)]
+              (48, 11, 2), (48, 13, 2), (16, 11, 2), (16, 13, 2), (32, 5, 2), (32, 15, 2), (48, 5, 2), (64, 15, 4), (128, 15, 8)]
 
 
 @pytest.mark.parametrize("D,w,lpp", RING_TABLE)

@@ -10,7 +10,8 @@ st = torch.cuda.current_stream().cuda_stream
 out = {}
 for (W, H, B) in ((1280, 720, 64), (640, 480, 128), (320, 240, 256)):
     for (D, w) in ((64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9),
-                   (128, 7), (128, 9), (128, 11), (64, 11), (64, 13), (128, 13), (96, 7), (96, 9), (96, 11), (96, 13), (48, 11), (48, 13)):
+                   (128, 7), (128, 9), (128, 11), (64, 11), (64, 13), (128, 13), (96, 7), (96, 9), (96, 11), (96, 13), (48, 11), (48, 13),
+                   (16, 11), (16, 13), (32, 5), (32, 15), (48, 5), (64, 15), (128, 15)):
         dL = torch.empty((B, H, W), dtype=torch.uint8, device="cuda"); dR = torch.empty_like(dL)
         dD = torch.empty((B, H, W), dtype=torch.int16, device="cuda")
         pkg.synth_pairs_device(dL, dR, first_frame=0, numDisparities=D, stream=st)
