@@ -37,7 +37,8 @@ print("checked", count, "mismatches", bad, variants, flush=True)
 # ---- second part: the ring kernel's own table on taller frames and device batches (strip boundaries, the 16-bit cap of
 # ---- a strip, the side-stream border kernel, the autotuned strip count on the second and third call)
 RING = [(64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9),
-        (128, 7), (128, 9), (128, 11), (64, 9), (64, 7), (128, 11), (96, 9), (96, 13), (48, 13), (64, 13), (128, 13), (96, 11)]
+        (128, 7), (128, 9), (128, 11), (64, 9), (64, 7), (128, 11), (96, 9), (96, 13), (48, 13), (64, 13), (128, 13), (96, 11),
+        (64, 15), (128, 15), (32, 15), (48, 5), (32, 5), (16, 13), (16, 11), (48, 11), (64, 11), (96, 7)]
 st = torch.cuda.current_stream().cuda_stream
 for seed in range(first, first + max(1, count // 10)):
     rng = np.random.default_rng(seed + 777)
