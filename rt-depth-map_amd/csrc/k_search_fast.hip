@@ -37,6 +37,7 @@ struct FastGeom {
     // grid the share depended on gridDim.x mod 8 and the search ran up to 1.5x slower for unlucky shapes.
     unsigned nfast, nborder;   // workgroups of each kind over the whole batch
     unsigned gfast, gborder;   // groups of 8
+    int xcd_local;             // tiles only: contiguous runs of items per XCD (RTDM_FAST_XCD=0: plain order)
 };
 
 template <int D, int NP>
@@ -112,7 +113,10 @@ __global__ __launch_bounds__(256, (FAST_TIGHT_BOUNDS ? (D >= 192 ? 3 : D >= 128 
         border_body<(D + 63) / 64>((unsigned char*)lds, Lp, Rp, disp, cost, g, bg, (int)(id % fg.bgx), (int)(id / fg.bgx), (int)fr);
         return;
     }
-    const unsigned fi = (grp - nb) * 8 + slot;
+    unsigned fi = (grp - nb) * 8 + slot;
+    // no border workgroups in the grid (batches: they run on a side stream): XCD `slot` takes the contiguous run of items
+    // [slot gfast, (slot + 1) gfast), so that the tiles of a strip and the strips of a frame share one L2 (k_search_ring.hip)
+    if (fg.gborder == 0 && fg.xcd_local) fi = slot * fg.gfast + grp;
     if (fi >= fg.nfast) return;
     const int b_tile = (int)(fi % fg.tiles), b_strip = (int)((fi / fg.tiles) % fg.strips), b_frame = (int)(fi / (fg.tiles * fg.strips));
 
@@ -307,6 +311,8 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     }
     fg.nfast = (unsigned)tiles * strips * n; fg.nborder = (unsigned)(fg.bgx * fg.bgy) * n;
     fg.gfast = (fg.nfast + 7) / 8; fg.gborder = (fg.nborder + 7) / 8;
+    static const int xcd_local = [] { const char* e = getenv("RTDM_FAST_XCD"); return e ? atoi(e) : 1; }();
+    fg.xcd_local = xcd_local;
     if (ldsb > 48 * 1024) (void)hipFuncSetAttribute((const void*)k_search_fast<D, NP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
     hipLaunchKernelGGL((k_search_fast<D, NP>), dim3((fg.gfast + fg.gborder) * 8), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, fg, bg);
 }
