@@ -90,3 +90,16 @@ def test_makefile_build_hip_rule_compiles_a_kernel_under_the_reference_kbuild(tm
     dry = subprocess.run(["make", "-n", "-f", "Makefile.build", "obj=hip-matcher/", "_all", "CC=g++", "CFLAGS=-O2"], cwd=tmp_path,
                          capture_output=True, text=True)
     assert dry.returncode == 0 and "g++ -O2 -c hip-matcher/glue.cpp" in dry.stdout, dry.stdout + dry.stderr
+
+
+def test_every_device_object_depends_on_every_device_header():
+    # a header edit that leaves an object stale once let an untested kernel change through: `make -W header -n` must want to
+    # recompile every translation unit
+    import glob
+    pkgdir = os.path.join(ROOT, "rt-depth-map_amd")
+    units = sorted(os.path.basename(p) for p in glob.glob(os.path.join(pkgdir, "csrc", "*.hip")))
+    for hdr in sorted(glob.glob(os.path.join(pkgdir, "csrc", "*.h"))) + [os.path.join(ROOT, "include", "rtdm.h")]:
+        rel = os.path.relpath(hdr, pkgdir)
+        out = subprocess.run(["make", "-n", "-W", rel], cwd=pkgdir, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+        rebuilt = sorted({os.path.basename(w) for line in out.splitlines() if " -c " in line for w in line.split() if w.endswith(".hip")})
+        assert rebuilt == units, (rel, rebuilt)
