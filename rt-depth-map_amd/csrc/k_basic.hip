@@ -691,17 +691,29 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     bool ha_loaded = false;
     const uint32_t* hc = (const uint32_t*)headmap + (size_t)(f * H + y) * (Ws >> 3) + (x0 >> 3);   // COMPACT: this chunk's records
     uint32_t ca = (COMPACT && inb) ? hc[0] : 0u;
+    // COMPACT: the strip's RS further rows and head records are requested up front (with a load, a wait and the union
+    // queue's atomics per row, a wave kept one row in flight); rows past the strip's end repeat its last one and are not used
+    Short8 rows[COMPACT ? RS : 1];
+    uint32_t heads[COMPACT ? RS : 1];
+    if constexpr (COMPACT) {
+#pragma unroll
+        for (int r = 0; r < RS; ++r) {
+            const int rr = r < nr ? r + 1 : nr;
+            rows[r] = a8; heads[r] = 0u;
+            if (inb) { rows[r] = *(const Short8*)(d + (size_t)rr * disp.pitch_e); heads[r] = hc[(size_t)rr * (Ws >> 3)]; }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < RS; ++r) {
         unsigned cm = 0;
         if (r < nr) {
-            b8 = *(const Short8*)(d + disp.pitch_e);
+            if constexpr (COMPACT) b8 = rows[r]; else b8 = *(const Short8*)(d + disp.pitch_e);
 #pragma unroll
             for (int k = 0; k < 8; ++k) cm |= (unsigned)conn(a8.v[k], b8.v[k], newVal, maxDiff) << k;
             cm &= colmask;
         }
         if constexpr (COMPACT) {
-            const uint32_t cb = r < nr ? hc[(size_t)(r + 1) * (Ws >> 3)] : 0u;
+            const uint32_t cb = r < nr ? heads[r] : 0u;
             // contact bit of the pixel left of the chunk: lane-1's bit 7, or (first lane of a wave) from memory
             unsigned leftc = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(cm >> 7), 0x138, 0xf, 0xf, false);   // wave_shr:1
             if ((threadIdx.x & 63) == 0) leftc = (cm && x0 > 0) ? (unsigned)conn(d[-1], d[disp.pitch_e - 1], newVal, maxDiff) : 0u;
