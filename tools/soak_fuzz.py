@@ -15,6 +15,7 @@ count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 bad = 0
 variants = {}
 for seed in range(first, first + count):
+    if (seed - first) % 500 == 0: print("case", seed - first, "mismatches so far", bad, flush=True)   # (a silent run looks hung)
     rng = np.random.default_rng(seed)
     W, H, kw, roi1, roi2 = tf._case(rng)
     L, R = pkg.synth.make_pair(seed, W, H, kw["numDisparities"])
@@ -41,6 +42,7 @@ RING = [(64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7)
         (64, 15), (128, 15), (32, 15), (48, 5), (32, 5), (16, 13), (16, 11), (48, 11), (64, 11), (96, 7)]
 st = torch.cuda.current_stream().cuda_stream
 for seed in range(first, first + max(1, count // 10)):
+    if (seed - first) % 100 == 0: print("ring case", seed - first, "mismatches so far", bad, flush=True)
     rng = np.random.default_rng(seed + 777)
     D, w = RING[int(rng.integers(0, len(RING)))]
     W, H = int(rng.integers(D + w + 40, D + w + 700)), int(rng.integers(w + 40, 420))
