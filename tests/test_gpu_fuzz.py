@@ -87,7 +87,7 @@ def test_random_sgm_configuration(pkg, oracle, synth, seed):
     assert np.array_equal(got, want), (seed, W, H, D, kw, int((got != want).sum()))
 
 
-FAST_TABLE = [(D, np_) for D in (16, 32, 48, 64, 96, 128, 192, 256) for np_ in (2, 3, 4)] + \
+FAST_TABLE = [(D, np_) for D in range(16, 257, 16) for np_ in (2, 3, 4)] + \
              [(D, np_) for D in (32, 64, 128) for np_ in (5, 6)]
 
 
