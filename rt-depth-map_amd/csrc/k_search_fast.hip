@@ -324,7 +324,9 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     X(64, 2) X(64, 3) X(64, 4) X(64, 5) X(64, 6) X(96, 2) X(96, 3) X(96, 4)                               \
     X(128, 2) X(128, 3) X(128, 4) X(128, 5) X(128, 6) X(192, 2) X(192, 3) X(192, 4) X(256, 2) X(256, 3) X(256, 4)    \
     X(80, 2) X(80, 3) X(80, 4) X(112, 2) X(112, 3) X(112, 4) X(144, 2) X(144, 3) X(144, 4) X(160, 2) X(160, 3) X(160, 4)  \
-    X(176, 2) X(176, 3) X(176, 4) X(208, 2) X(208, 3) X(208, 4) X(224, 2) X(224, 3) X(224, 4) X(240, 2) X(240, 3) X(240, 4)
+    X(176, 2) X(176, 3) X(176, 4) X(208, 2) X(208, 3) X(208, 4) X(224, 2) X(224, 3) X(224, 4) X(240, 2) X(240, 3) X(240, 4)  \
+    X(16, 5) X(16, 6) X(48, 5) X(48, 6) X(80, 5) X(80, 6) X(96, 5) X(96, 6) X(112, 5) X(112, 6) X(144, 5) X(144, 6)          \
+    X(160, 5) X(160, 6) X(176, 5) X(176, 6) X(192, 5) X(192, 6)
 
 bool fast_search_supported(const BMGeom& g)
 {

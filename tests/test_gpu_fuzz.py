@@ -88,7 +88,7 @@ def test_random_sgm_configuration(pkg, oracle, synth, seed):
 
 
 FAST_TABLE = [(D, np_) for D in range(16, 257, 16) for np_ in (2, 3, 4)] + \
-             [(D, np_) for D in (32, 64, 128) for np_ in (5, 6)]
+             [(D, np_) for D in range(16, 193, 16) for np_ in (5, 6)]
 
 
 @pytest.mark.parametrize("D,pieces", FAST_TABLE)
