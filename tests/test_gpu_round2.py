@@ -114,8 +114,9 @@ def test_roi_moving_batched_caller_keeps_flat_call_time(pkg, synth):
         m.compute_device(dL, dR, dD, st)
         torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
     t = np.array(times[2:])
-    # a tuning pass is ~30 extra launches and shows up as a >10x outlier; growth with the ROI area is < 4x over the run
-    assert t.max() < 6 * np.median(t), times
+    # a tuning pass is ~30 extra launches and shows up as a >10x outlier -- for every new ROI if the table were keyed on
+    # positions; growth with the ROI area is < 4x over the run.  (Two stray outliers are allowed: a shared box hiccups.)
+    assert int((t > 6 * np.median(t)).sum()) <= 2, times
     m.close()
 
 
