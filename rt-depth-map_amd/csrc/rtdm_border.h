@@ -121,13 +121,24 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
     for (int s0 = 0; s0 < nsteps; s0 += RB) {
         const int nb = min(RB, nsteps - s0);
         int nrec = 0;
-        for (int b = 0; b < nb; ++b) {
-            const int row = ys0 - r + s0 + b;
+        // the batch's rows are all requested before any of them is stored (a load, a wait and a store per row made the walk
+        // eight dependent memory round trips per batch: the kernel's whole latency); stage_dw <= 128: two dwords per lane and row
+        uint32_t rv[RB][2];
+        uint8_t lv[RB];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+            const int row = ys0 - r + s0 + min(b, nb - 1);
             const uint32_t* rrow = (const uint32_t*)(Rb + (size_t)row * Rp.pitch + ra);    // plane pitches are multiples of 64
+            rv[b][0] = lane < stage_dw ? rrow[lane] : 0u;
+            rv[b][1] = lane + 64 < stage_dw ? rrow[lane + 64] : 0u;
+            lv[b] = lane < w ? Lb[(size_t)row * Lp.pitch + min(max(g.lofs + j0 + lane, 0), W - 1)] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
             uint32_t* rdst = (uint32_t*)(Rbuf + b * rsp);
-            for (int i = lane; i < stage_dw; i += 64) rdst[i] = rrow[i];
-            if (lane < 4 * ndw)
-                Lbuf[b * 32 + lane] = lane < w ? Lb[(size_t)row * Lp.pitch + min(max(g.lofs + j0 + lane, 0), W - 1)] : (uint8_t)0;
+            if (lane < stage_dw) rdst[lane] = rv[b][0];
+            if (lane + 64 < stage_dw) rdst[lane + 64] = rv[b][1];
+            if (lane < 4 * ndw) Lbuf[b * 32 + lane] = lv[b];
         }
         __builtin_amdgcn_wave_barrier();
         for (int b = 0; b < nb; ++b) {
