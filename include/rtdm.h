@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTDM_ABI_VERSION 1
+#define RTDM_ABI_VERSION 2   /* 2: rtdm_bm_params.legacy_right_clamp, rtdm_bm_get_tuner_stats */
 
 typedef enum rtdm_status {
     RTDM_OK = 0,
@@ -47,6 +47,12 @@ typedef struct rtdm_bm_params {
     int speckleWindowSize; /* <= 0 disables the speckle filter */
     int speckleRange;      /* compared unscaled against the x16 fixed-point disparities */
     int disp12MaxDiff;     /* < 0 disables the left-right check */
+    /* 0 (default): the right image's window samples are clamped as in OpenCV 4.x (column <= W - numDisparities, so
+     * base + d stays inside the row).  1: the rule of the 3.1-3.2 era the reference links (Makefile.include:18-23):
+     * the base is clamped to W - rofs - 1 and base + d runs on into the following bytes of a step == W plane, i.e. into
+     * the next row (zeros after the last row).  Only the last blockSize/2 searched columns differ, and they reach the
+     * result only as voters of the left-right check (oracle/rtdm_oracle.h, hazard H1).  Still unpinned: no OpenCV here. */
+    int legacy_right_clamp;
 } rtdm_bm_params;
 
 typedef struct rtdm_bm rtdm_bm;       /* one matcher = one GPU + one HIP stream + its workspace */
@@ -110,6 +116,9 @@ int rtdm_bm_get_stage_time(rtdm_bm* bm, int stage, double* total_ms, long* launc
 int rtdm_bm_reset_stage_times(rtdm_bm* bm);
 /* Name of the SAD-search kernel variant the current parameters select ("generic_u16", ...). */
 const char* rtdm_bm_search_variant(const rtdm_bm* bm);
+/* Diagnostic counters of the strip-count tuner inside rtdm_bm_compute_device (it times a few search launches the second
+ * time a batch shape is seen): shapes measured so far and the extra search launches that took.  Either pointer may be NULL. */
+int rtdm_bm_get_tuner_stats(const rtdm_bm* bm, long* shapes_measured, long* timing_launches);
 /* Diagnostic A/B switch, process wide: which of the hand-written search kernels may be chosen for configurations that
  * several cover.  0: k_search_fast only; 1: k_search_ring where it is instantiated; 2 / 4 / 8: as 1, with two / four / eight
  * lanes per pixel where that form of the ring kernel exists; -1 (default): the library's choice (environment RTDM_RING=0/1 and

@@ -38,7 +38,7 @@ class SGMParams(C.Structure):
 class BMParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "preFilterCap", "blockSize", "minDisparity", "numDisparities", "textureThreshold",
-        "uniquenessRatio", "speckleWindowSize", "speckleRange", "disp12MaxDiff")]
+        "uniquenessRatio", "speckleWindowSize", "speckleRange", "disp12MaxDiff", "legacy_right_clamp")]
 
 
 _lib = None
@@ -71,6 +71,7 @@ def lib():
         "rtdm_bm_get_stage_time": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "rtdm_bm_reset_stage_times": (C.c_int, [vp]),
         "rtdm_bm_search_variant": (C.c_char_p, [vp]),
+        "rtdm_bm_get_tuner_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
         "rtdm_debug_search_kernel": (None, [C.c_int]),
         "rtdm_morph_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
         "rtdm_morph_destroy": (None, [vp]),
@@ -115,7 +116,7 @@ def lib():
 EXPORTS = ("rtdm_strerror rtdm_last_hip_error rtdm_abi_version rtdm_device_count rtdm_bm_default_params "
            "rtdm_bm_create rtdm_bm_destroy rtdm_bm_set_roi rtdm_bm_get_params rtdm_bm_compute "
            "rtdm_bm_compute_device rtdm_bm_compute_batch rtdm_bm_synchronize rtdm_bm_set_profiling "
-           "rtdm_bm_get_stage_time rtdm_bm_reset_stage_times rtdm_bm_search_variant rtdm_debug_search_kernel rtdm_morph_create "
+           "rtdm_bm_get_stage_time rtdm_bm_reset_stage_times rtdm_bm_search_variant rtdm_bm_get_tuner_stats rtdm_debug_search_kernel rtdm_morph_create "
            "rtdm_morph_destroy rtdm_morph_in_buffer rtdm_morph_out_buffer rtdm_morph_run "
            "rtdm_morph_run_device rtdm_synth_pairs_device rtdm_sgm_default_params rtdm_sgm_create rtdm_sgm_destroy "
            "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_bm_compute_depth rtdm_depth_stats_device "
@@ -131,7 +132,7 @@ def check(status, where):
 
 
 def make_params(preFilterCap=31, blockSize=13, minDisparity=0, numDisparities=64, textureThreshold=10,
-                uniquenessRatio=10, speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1):
+                uniquenessRatio=10, speckleWindowSize=100, speckleRange=32, disp12MaxDiff=1, legacy_right_clamp=0):
     """Defaults are the reference's literals (main.cpp:134-135)."""
     return BMParams(preFilterCap, blockSize, minDisparity, numDisparities, textureThreshold,
-                    uniquenessRatio, speckleWindowSize, speckleRange, disp12MaxDiff)
+                    uniquenessRatio, speckleWindowSize, speckleRange, disp12MaxDiff, legacy_right_clamp)

@@ -200,8 +200,7 @@ void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, 
 {
     const auto al16 = [](const Plane8& p) { return (((size_t)p.base | p.pitch | p.frame) & 15) == 0; };
     const size_t w16 = (size_t)((W + 15) & ~15);
-    static int strip16 = -1;
-    if (strip16 < 0) { const char* e = getenv("RTDM_PREFILTER_STRIP"); strip16 = e ? atoi(e) : 1; }
+    static const int strip16 = env_int("RTDM_PREFILTER_STRIP", 1);
     if (strip16 && al16(L) && al16(R) && L.pitch >= w16 && R.pitch >= w16 && ((size_t)Lp.base & 15) == 0 && ((size_t)Rp.base & 15) == 0) {
         constexpr int RY = 8;
         const int nxb = (W + 15) / 16;
@@ -293,8 +292,7 @@ void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int val
 // segment) and only every R-th pair is left to k_spk_merge.
 static int lr_rows()   // rows per workgroup when the speckle init is fused (RTDM_LR_ROWS = 1 | 2 | 4)
 {
-    static int r = 0;
-    if (!r) { const char* e = getenv("RTDM_LR_ROWS"); r = e ? atoi(e) : 1; if (r != 1 && r != 2 && r != 4) r = 1; }
+    static const int r = [] { const int v = env_int("RTDM_LR_ROWS", 1); return (v == 1 || v == 2 || v == 4) ? v : 1; }();
     return r;
 }
 
@@ -838,8 +836,7 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         const bool vec = (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2)) & 15) == 0 && (Ws & 7) == 0 &&
                          disp.pitch_e >= (size_t)((W + 7) & ~7);   // a ragged last chunk reads (never writes) padding columns
         dim3 grid((nxb * npairs + 255) / 256, n);
-        static int rs = -1;
-        if (rs < 0) { const char* e = getenv("RTDM_MERGE_STRIP"); rs = e ? atoi(e) : 4; }
+        static const int rs = env_int("RTDM_MERGE_STRIP", 4);
         if (compact_heads) {                       // written by k_lrcheck_vec, whose alignment conditions imply `vec` and step == 1
             dim3 sgrid((nxb * ((npairs + 3) / 4) + 255) / 256, n);
             hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);

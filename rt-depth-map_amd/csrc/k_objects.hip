@@ -6,6 +6,7 @@
 // are united 8-connected, background pixels 4-connected, background on the image border with a virtual frame node
 // (index W*H).  Roots are the smallest index of a set = the component's first pixel in raster order, which is what
 // decides both the contour order and (through the background left of it) whether the component is external.
+#include <mutex>
 #include "rtdm_kernels.h"
 #include "rtdm_device.h"
 
@@ -132,14 +133,17 @@ __global__ __launch_bounds__(256) void k_cc_collect(const uint8_t* mask, size_t 
 void launch_hsv_inrange(const uint8_t* rgb, size_t pitch, int W, int H, const int lo[3], const int hi[3], uint8_t* mask,
                         size_t mpitch, hipStream_t stream)
 {
-    static bool tabs[64] = {};
+    // the tables live in device globals: filled once per device, and finished before any thread's launch can use them
+    // (std::call_once holds later callers back until the first has synchronised)
+    static std::once_flag tabs[64];
     int dev = 0;
     (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !tabs[dev]) {            // once per device, finished before anything can use the tables
+    const auto fill = [&] {
         hipLaunchKernelGGL(k_hsv_tabs, dim3(1), dim3(256), 0, stream);
         (void)hipStreamSynchronize(stream);
-        tabs[dev] = true;
-    }
+    };
+    if (dev >= 0 && dev < 64) std::call_once(tabs[dev], fill);
+    else fill();
     hipLaunchKernelGGL(k_hsv_inrange, dim3((W * H + 255) / 256), dim3(256), 0, stream, rgb, pitch, W, H, lo[0], lo[1], lo[2],
                        hi[0], hi[1], hi[2], mask, mpitch);
 }

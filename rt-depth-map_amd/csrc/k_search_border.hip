@@ -16,6 +16,7 @@
 #include "rtdm_border.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace rtdm {
 
@@ -29,8 +30,7 @@ bool border_search_supported(const BMGeom& g)
 // would otherwise consist of a handful of long, latency-bound walks (single frames: the reference's real-time case).
 static int border_rows(int nrows, int ncols, int n)
 {
-    static int rs_env = -1;
-    if (rs_env < 0) { const char* e = getenv("RTDM_BORDER_RS"); rs_env = e ? atoi(e) : 0; }
+    static const int rs_env = env_int("RTDM_BORDER_RS", 0);
     if (rs_env >= 8) return rs_env;
     const long want = (long)nrows * ((ncols + 3) / 4) * n / 256;     // rows per workgroup that still leave >= 256 workgroups
     return (int)std::min(128L, std::max(16L, want));
@@ -65,12 +65,19 @@ void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const
     const size_t per_wave = ((size_t)RB * bg.rsp + (size_t)RB * 32 + (size_t)g.w * (nch * 64) * 2 + (size_t)g.w * 4 + 15) & ~(size_t)15;
     const size_t lds = per_wave * 4;
     dim3 grid((ncols + 3) / 4, (nrows + bg.rs - 1) / bg.rs, n), block(256);
-    switch (nch) {
-        case 1: hipLaunchKernelGGL(k_search_border<1>, grid, block, lds, stream, Lp, Rp, disp, (uint16_t*)cost, g, bg); break;
-        case 2: hipLaunchKernelGGL(k_search_border<2>, grid, block, lds, stream, Lp, Rp, disp, (uint16_t*)cost, g, bg); break;
-        case 3: hipLaunchKernelGGL(k_search_border<3>, grid, block, lds, stream, Lp, Rp, disp, (uint16_t*)cost, g, bg); break;
-        default: hipLaunchKernelGGL(k_search_border<4>, grid, block, lds, stream, Lp, Rp, disp, (uint16_t*)cost, g, bg); break;
-    }
+    const auto go = [&](auto nc, auto lg) {
+        hipLaunchKernelGGL((k_search_border<decltype(nc)::value, decltype(lg)::value>), grid, block, lds, stream, Lp, Rp, disp, (uint16_t*)cost, g, bg);
+    };
+    const auto pick = [&](auto lg) {
+        switch (nch) {
+            case 1: go(std::integral_constant<int, 1>{}, lg); break;
+            case 2: go(std::integral_constant<int, 2>{}, lg); break;
+            case 3: go(std::integral_constant<int, 3>{}, lg); break;
+            default: go(std::integral_constant<int, 4>{}, lg); break;
+        }
+    };
+    if (g.legacy) pick(std::true_type{});
+    else pick(std::false_type{});
 }
 
 }  // namespace rtdm

@@ -291,8 +291,7 @@ static void launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BM
     // tail in the last scheduling round (4 workgroups/CU resident => 1024 slots).  With K = tiles*n/1024 rounds per strip
     // the time is ~ (nrows/strips + h)(K*strips + 1/2), h = (w-1)/2, minimal at strips = sqrt(nrows / ((w-1) K)).
     // RTDM_FAST_WGS=<total workgroups> overrides (sweeps: tools/sweep_strips.sh, tools/sweep_wgs_small.py).
-    static int target_wgs = -1;
-    if (target_wgs < 0) { const char* e = getenv("RTDM_FAST_WGS"); target_wgs = e ? atoi(e) : 0; }
+    static const int target_wgs = env_int("RTDM_FAST_WGS", 0);
     int strips;
     if (strips_hint > 0) strips = strips_hint;                      // measured choice (rtdm_api.hip, tune_strips)
     else if (target_wgs > 0) strips = (target_wgs + tiles * n - 1) / (tiles * n);

@@ -58,11 +58,12 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
     int16_t* db = disp.base + (size_t)f * disp.frame_e;
 
     // sample-column tables; rb0 = right base of the first sample column (clamps are monotone)
-    const int rb0 = min(max(g.rofs + x_tile - r, 0), g.W - D);
+    const int Wc = g.legacy ? g.W - g.rofs - 1 : g.W - D;      // largest right sample base (rtdm_bm_params.legacy_right_clamp)
+    const int rb0 = min(max(g.rofs + x_tile - r, 0), Wc);
     for (int jj = tid; jj < TCH; jj += 256) {
         const int j = x_tile + jj - r;
         lidx[jj] = (short)min(max(g.lofs + j, 0), g.W - 1);
-        ridx[jj] = (short)(min(max(g.rofs + j, 0), g.W - D) - rb0);
+        ridx[jj] = (short)(min(max(g.rofs + j, 0), Wc) - rb0);
         Tcol[jj] = 0;
     }
     for (int i = tid; i < D * TCH; i += 256) V[i] = 0;
@@ -80,10 +81,15 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
             const uint8_t* lrow_o = Lb + (size_t)(sub ? row_out : row_in) * Lp.pitch;
             const uint8_t* rrow_o = Rb + (size_t)(sub ? row_out : row_in) * Rp.pitch;
             for (int jj = tid; jj < TCH; jj += 256) { Ln[jj] = lrow[lidx[jj]]; Lo[jj] = lrow_o[lidx[jj]]; }
+            // legacy clamp: base + e addresses a plane of step W -- past the row's end come the next row's first bytes
+            const int rin1 = row_in + 1, rout1 = (sub ? row_out : row_in) + 1;
+            const uint8_t* rnext = Rb + (size_t)min(rin1, g.H - 1) * Rp.pitch;
+            const uint8_t* rnext_o = Rb + (size_t)min(rout1, g.H - 1) * Rp.pitch;
             for (int k = tid; k < TCH + D; k += 256) {
                 const int x = rb0 + k;
-                Rn[k] = x < g.W ? rrow[x] : 0;
-                Ro[k] = x < g.W ? rrow_o[x] : 0;
+                const bool wrap = g.legacy && x >= g.W && x - g.W < g.W;
+                Rn[k] = x < g.W ? rrow[x] : (wrap && rin1 < g.H) ? rnext[x - g.W] : 0;
+                Ro[k] = x < g.W ? rrow_o[x] : (wrap && rout1 < g.H) ? rnext_o[x - g.W] : 0;
             }
         }
         __syncthreads();

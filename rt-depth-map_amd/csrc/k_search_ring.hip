@@ -479,9 +479,16 @@ static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g
                            X(128, 7, 8) X(128, 9, 8) X(128, 11, 8) X(128, 13, 8) X(96, 7, 4) X(96, 9, 4) X(96, 11, 4) X(96, 13, 4) X(48, 11, 2) X(48, 13, 2) \
                            X(16, 11, 2) X(16, 13, 2) X(32, 5, 2) X(32, 15, 2) X(48, 5, 2) X(64, 15, 4) X(128, 15, 8)
 
-static int g_ring_mode = -1;            // rtdm_debug_search_kernel: 0 never, 1 wherever instantiated, -1 default;
-static int g_ring_lpp = 0;              //   2 / 4: wherever instantiated, with that many lanes per pixel where that form exists
-void ring_set_mode(int mode) { g_ring_mode = mode < 0 ? -1 : mode == 0 ? 0 : 1; g_ring_lpp = (mode == 2 || mode == 4 || mode == 8) ? mode : 0; }
+// rtdm_debug_search_kernel (a process-wide A/B switch; one atomic word so that a launch on another thread sees a consistent
+// pair): low byte = mode + 1 (0 never, 1 wherever instantiated, -1 default), next byte = lanes per pixel to force (0: none)
+static std::atomic<int> g_ring_switch{0};
+void ring_set_mode(int mode)
+{
+    const int m = mode < 0 ? -1 : mode == 0 ? 0 : 1, lpp = (mode == 2 || mode == 4 || mode == 8) ? mode : 0;
+    g_ring_switch.store((m + 1) | (lpp << 8), std::memory_order_relaxed);
+}
+static int ring_mode() { return (g_ring_switch.load(std::memory_order_relaxed) & 0xff) - 1; }
+static int ring_forced_lpp() { return g_ring_switch.load(std::memory_order_relaxed) >> 8; }
 
 // lanes per pixel for a configuration (0: not instantiated).  RTDM_RING_LPP = 2 / 4 forces one form where it exists (A/B).
 static int ring_lpp(const BMGeom& g)
@@ -491,7 +498,7 @@ static int ring_lpp(const BMGeom& g)
 #define X(DD, WW, LL) if (g.D == DD && g.w == WW) have |= LL;
     RTDM_RING_TABLE(X)
 #undef X
-    const int want = g_ring_lpp ? g_ring_lpp : env;
+    const int forced = ring_forced_lpp(), want = forced ? forced : env;
     if (want && (have & want) == want) return want;
     // measured (tools/ab_ring.py): more lanes per pixel win where the ring holds the two-lane form at two waves per SIMD
     return (have & 8) ? 8 : (have & 4) ? 4 : (have & 2) ? 2 : 0;
@@ -572,12 +579,14 @@ static bool ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
     const auto launch = [&](auto Fc) {
         constexpr bool F = decltype(Fc)::value;
         if (ldsb > 48 * 1024) {                     // once per device of this process (a handle lives on one device)
-            static unsigned long long done = 0;
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (dev >= 64 || !((done >> dev) & 1)) {
-                (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS, LPP, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max(ldsb, (size_t)64 * 1024));
-                if (dev < 64) done |= 1ull << dev;
+            // (one flag per instantiation; a second thread that races the first caller on the same device sets the same value)
+            static OncePerDevice once;
+            static std::atomic<size_t> granted{0};
+            const size_t want = max(ldsb, (size_t)64 * 1024);
+            if (once.first() || granted.load(std::memory_order_acquire) < want) {
+                (void)hipFuncSetAttribute((const void*)k_search_ring<D, WS, LPP, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+                size_t g0 = granted.load(std::memory_order_relaxed);
+                while (g0 < want && !granted.compare_exchange_weak(g0, want, std::memory_order_release)) {}
             }
         }
         hipLaunchKernelGGL((k_search_ring<D, WS, LPP, F>), dim3(grid + rg.nborder), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg, bg);
@@ -592,7 +601,7 @@ static bool ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
 bool ring_search_supported(const BMGeom& g)
 {
     static const int env = [] { const char* e = getenv("RTDM_RING"); return e ? atoi(e) : -1; }();   // A/B switch
-    const int mode = g_ring_mode >= 0 ? g_ring_mode : env;
+    const int sw = ring_mode(), mode = sw >= 0 ? sw : env;
     if (mode == 0) return false;
     if (2L * g.cap * g.w * g.w > 32766) return false;       // packed u16 sums + the T+1 <= 32767 argument of the selection
     if (ring_rows_cap(g) < 2) return false;

@@ -466,8 +466,7 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     const int threads = (g.D + 63) & ~63;
     int npl = (g.D + 63) / 64;                       // disparities per lane of the wave-per-line kernel: must divide D
     if (g.D % npl) npl = 4;
-    static int wave_paths = -1;
-    if (wave_paths < 0) { const char* e = getenv("RTDM_SGM_WAVE_PATHS"); wave_paths = e ? atoi(e) : 1; }
+    static const int wave_paths = env_int("RTDM_SGM_WAVE_PATHS", 1);
     const bool aligned = (((size_t)b.C | (size_t)b.S) & 7) == 0;
     for (int k = 0; k < 8; ++k) {
         const int dx = dirs[k][0], dy = dirs[k][1];

@@ -28,6 +28,20 @@ static thread_local std::string g_hip_err;
 
 struct StageEvent { hipEvent_t a, b; int stage; int frames; };
 
+// Host entry points hand the caller's (possibly page-locked) planes to async copies: whatever way they leave, nothing may
+// still be in flight from / to those planes.  Success paths synchronise themselves and disarm the guard.
+struct DrainOnError {
+    hipStream_t s;
+    bool armed = true;
+    ~DrainOnError()
+    {
+        if (!armed) return;
+        const std::string first = g_hip_err;
+        (void)hipStreamSynchronize(s); (void)hipGetLastError();
+        g_hip_err = first;
+    }
+};
+
 // Shape of a batched search launch, compared field by field (tune_strips).
 struct TuneKey {
     int W, H, n, ncols, nrows, fuse;
@@ -68,6 +82,7 @@ struct rtdm_bm {
     uint8_t *dInL, *dInR;          // staging for the host entry points
     int16_t* dOut;                 //                      [maxB][maxH][maxW]
     std::vector<TuneEntry> tuned;  // measured strip counts per work shape, least recently used first (<= 16 entries)
+    long tune_shapes, tune_launches;   // rtdm_bm_get_tuner_stats
     int32_t *dCost, *dLabel, *dSize, *dRowCnt;
     uint32_t* dRuns;
     int16_t* dHead;
@@ -123,7 +138,7 @@ void rtdm_bm_default_params(rtdm_bm_params* p, int numDisparities)
     if (!p) return;
     p->preFilterCap = 31; p->blockSize = 13; p->minDisparity = 0; p->numDisparities = numDisparities;
     p->textureThreshold = 10; p->uniquenessRatio = 10; p->speckleWindowSize = 100; p->speckleRange = 32;
-    p->disp12MaxDiff = 1;
+    p->disp12MaxDiff = 1; p->legacy_right_clamp = 0;
 }
 
 static int validate_params(const rtdm_bm_params& p)
@@ -134,6 +149,7 @@ static int validate_params(const rtdm_bm_params& p)
     if (p.textureThreshold < 0 || p.uniquenessRatio < 0) return RTDM_ERR_BAD_PARAM;
     // the x16 fixed-point output is 16 bits wide: (minDisparity - 1) * 16 .. (minDisparity + numDisparities) * 16 must fit
     if (p.minDisparity < -2047 || (long)p.minDisparity + p.numDisparities > 2047) return RTDM_ERR_BAD_PARAM;
+    if (p.legacy_right_clamp != 0 && p.legacy_right_clamp != 1) return RTDM_ERR_BAD_PARAM;
     return RTDM_OK;
 }
 
@@ -164,6 +180,7 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     bm->p = *params; bm->maxW = max_width; bm->maxH = max_height; bm->maxB = max_batch; bm->device = device;
     for (int i = 0; i < 4; ++i) bm->roi1[i] = bm->roi2[i] = 0;
     bm->profiling = false;
+    bm->tune_shapes = bm->tune_launches = 0;
     for (int i = 0; i < RTDM_NUM_STAGES; ++i) { bm->stage_ms[i] = 0; bm->stage_launches[i] = 0; bm->stage_frames[i] = 0; }
     bm->ppitch = ((size_t)max_width + 63) & ~(size_t)63;
     const size_t plane = bm->ppitch * max_height * (size_t)max_batch;
@@ -291,6 +308,7 @@ static bool make_geom(const rtdm_bm* bm, int W, int H, BMGeom* g)
     g->want_cost = p.disp12MaxDiff >= 0;
     g->cost16 = 2L * p.preFilterCap * p.blockSize * p.blockSize < 65536;
     g->mask_cols = p.disp12MaxDiff < 0;
+    g->legacy = p.legacy_right_clamp;
     int r1[4] = {0, 0, W, H}, r2[4] = {0, 0, W, H};
     if (bm->roi1[2] > 0 && bm->roi1[3] > 0) std::copy(bm->roi1, bm->roi1 + 4, r1);
     if (bm->roi2[2] > 0 && bm->roi2[3] > 0) std::copy(bm->roi2, bm->roi2 + 4, r2);
@@ -344,9 +362,8 @@ static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plan
         if (ring) launch_search_ring(Lpr, Rpr, disp, ln.dCost, g, n, s, c, fuse);
         else launch_search_fast(Lpr, Rpr, disp, ln.dCost, g, n, s, fuse, c);
     };
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("RTDM_AUTOTUNE"); enabled = e ? atoi(e) : 1; }
-    if (!enabled || n < 16 || getenv("RTDM_FAST_WGS")) return 0;
+    static const bool enabled = env_int("RTDM_AUTOTUNE", 1) != 0 && getenv("RTDM_FAST_WGS") == nullptr;
+    if (!enabled || n < 16) return 0;
     TuneKey key{g.W, g.H, n, g.cx1 - g.cx0, g.vy1 - g.vy0, (fuse ? 1 : 0) | (ring ? ring_lanes_per_pixel(g) : 0)};
     for (size_t i = 0; i < bm->tuned.size(); ++i) {
         if (!(bm->tuned[i].key == key)) continue;
@@ -354,6 +371,7 @@ static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plan
         bm->tuned.erase(bm->tuned.begin() + (long)i);              // most recently used goes to the back
         if (e.strips == 0) {
             e.strips = -1;                                          // being measured: a failure below leaves the model in charge
+            ++bm->tune_shapes;
             const int model = ring ? ring_strips_model(g, n) : fast_strips_model(g, n), cap = (g.vy1 - g.vy0 + 15) / 16;
             int best = model;
             float best_ms = 1e30f;
@@ -369,6 +387,7 @@ static int tune_strips(rtdm_bm* bm, const Lane& ln, Plane8 Lpr, Plane8 Rpr, Plan
                         if (dup) continue;
                         seen[nseen++] = c;
                         launch(c);          // warm
+                        bm->tune_launches += 3;
                         float ms = 1e30f;
                         for (int rep = 0; rep < 2; ++rep) {
                             (void)hipEventRecord(a, s);
@@ -461,7 +480,8 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
             // (search -2 %).  Single frames keep the fused launch (one kernel less).  RTDM_BORDER_ASYNC=0: always fused.
             static const bool async_border = [] { const char* e = getenv("RTDM_BORDER_ASYNC"); return !e || atoi(e) != 0; }();
             const bool side = async_border && border_search_supported(g) && n >= 16;
-            const bool fuse = border_search_supported(g) && !separate && !side;   // border workgroups inside the tile kernel's grid
+            // (the 3.x clamp exists in the stand-alone border kernel only: the fused forms keep their register budget)
+            const bool fuse = border_search_supported(g) && !separate && !side && !g.legacy;   // border workgroups inside the tile kernel's grid
             // (measured, if at all, before the side stream forks: nothing else runs beside the timed launches)
             const int strips = tune_strips(bm, ln, Lpr, Rpr, disp, g, n, s, fuse, ring);
             if (side) {
@@ -562,8 +582,7 @@ int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint
     hipStream_t front = bm->lane[0].stream;
     HIPC(hipEventRecord(bm->evIn, s));
     HIPC(hipStreamWaitEvent(front, bm->evIn, 0));
-    static int npieces = 0;
-    if (!npieces) { const char* e = getenv("RTDM_PIECES"); npieces = e ? atoi(e) : 4; if (npieces < 2) npieces = 2; }
+    static const int npieces = std::max(2, env_int("RTDM_PIECES", 4));
     const int piece = std::max(1, std::min(bm->laneB, (n + npieces - 1) / npieces));
     bool used[2] = {false, false};
     int k = 0;
@@ -584,6 +603,9 @@ int rtdm_bm_compute_device(rtdm_bm* bm, int n, const uint8_t* d_left, const uint
     return RTDM_OK;
 }
 
+static int compute_batch_enqueue(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t* right, size_t pitch, size_t frame_stride,
+                                 int width, int height, int16_t* disp, size_t disp_pitch, size_t disp_frame_stride);
+
 int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t* right,
                           size_t pitch, size_t frame_stride, int width, int height,
                           int16_t* disp, size_t disp_pitch, size_t disp_frame_stride)
@@ -594,6 +616,21 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
     if (rc) return rc;
     if (pitch < (size_t)width || disp_pitch < (size_t)width * 2) return RTDM_ERR_BAD_SIZE;
     HIPC(hipSetDevice(bm->device));
+    rc = compute_batch_enqueue(bm, n, left, right, pitch, frame_stride, width, height, disp, disp_pitch, disp_frame_stride);
+    if (rc) {
+        // an error exit must not leave DMA in flight from / to the caller's buffers: it is free to release them once we return
+        const std::string first = g_hip_err;
+        (void)hipStreamSynchronize(bm->sIn); (void)hipStreamSynchronize(bm->stream); (void)hipStreamSynchronize(bm->sOut);
+        (void)hipGetLastError();
+        g_hip_err = first;
+    }
+    return rc;
+}
+
+static int compute_batch_enqueue(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t* right, size_t pitch, size_t frame_stride,
+                                 int width, int height, int16_t* disp, size_t disp_pitch, size_t disp_frame_stride)
+{
+    int rc = RTDM_OK;
     hipStream_t s = bm->stream;
     const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
     const size_t Ws = (size_t)((width + 7) & ~7);                      // the lane's internal plane (see run_chunk)
@@ -615,8 +652,10 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
         if (two && k >= 2) HIPC(hipStreamWaitEvent(si, bm->evComp[b], 0));      // the half's previous chunk has been consumed
         uint8_t *dl = bm->dInL + fo * dframe, *dr = bm->dInR + fo * dframe;
         if (pitch == dpitch && frame_stride == dframe) {               // the caller's frames have the staging layout: one copy per image
-            HIPC(hipMemcpyAsync(dl, left + (size_t)i0 * frame_stride, (size_t)m * dframe, hipMemcpyHostToDevice, si));
-            HIPC(hipMemcpyAsync(dr, right + (size_t)i0 * frame_stride, (size_t)m * dframe, hipMemcpyHostToDevice, si));
+            // (up to the last pixel of the last row: a view that starts at x > 0 of its parent plane ends before the row's pitch does)
+            const size_t nbytes = (size_t)m * dframe - (dpitch - (size_t)width);
+            HIPC(hipMemcpyAsync(dl, left + (size_t)i0 * frame_stride, nbytes, hipMemcpyHostToDevice, si));
+            HIPC(hipMemcpyAsync(dr, right + (size_t)i0 * frame_stride, nbytes, hipMemcpyHostToDevice, si));
         } else {
             for (int i = 0; i < m; ++i) {
                 HIPC(hipMemcpy2DAsync(dl + i * dframe, dpitch, left + (size_t)(i0 + i) * frame_stride, pitch, width, height, hipMemcpyHostToDevice, si));
@@ -634,7 +673,9 @@ int rtdm_bm_compute_batch(rtdm_bm* bm, int n, const uint8_t* left, const uint8_t
         rc = run_chunk(bm, bm->lane[0], m, L, R, width, height, O, s);
         if (rc) return rc;
         if (two) { HIPC(hipEventRecord(bm->evComp[b], s)); HIPC(hipStreamWaitEvent(so, bm->evComp[b], 0)); }
-        if (disp_pitch == opitch && disp_frame_stride == oframe) {
+        // one linear copy only when the internal rows carry no padding: with width < Ws it would write the pad columns
+        // [width, Ws) of the caller's rows, which are not part of the view
+        if ((size_t)width == Ws && disp_pitch == opitch && disp_frame_stride == oframe) {
             HIPC(hipMemcpyAsync((uint8_t*)disp + (size_t)i0 * disp_frame_stride, dout, (size_t)m * oframe, hipMemcpyDeviceToHost, so));
         } else {
             for (int i = 0; i < m; ++i)
@@ -658,6 +699,7 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
         return RTDM_ERR_BAD_SIZE;
     HIPC(hipSetDevice(bm->device));
     hipStream_t s = bm->stream;
+    DrainOnError drain{s};
     const size_t dpitch = bm->ppitch, dframe = bm->ppitch * (size_t)height;
     // The caller's Mats are pageable ROI views (estimator.cpp:33,36): the rows are gathered into the page-locked staging
     // area on the host and go over in linear async copies -- in two BANDS of rows per direction, so that the host gathers
@@ -676,6 +718,7 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
         if (rc) return rc;
         HIPC(hipMemcpy2DAsync(disp, disp_pitch, bm->dOut, Wsd * sizeof(int16_t), (size_t)width * sizeof(int16_t), height, hipMemcpyDeviceToHost, s));
         HIPC(hipStreamSynchronize(s));
+        drain.armed = false;
         return RTDM_OK;
     }
     uint8_t* hL = bm->hStage;
@@ -710,13 +753,14 @@ int rtdm_bm_compute(rtdm_bm* bm, const uint8_t* left, size_t left_pitch, const u
     for (int b = 0; b < nbo; ++b) {
         const int y0 = b * bh, y1 = std::min(height, y0 + bh);
         HIPC(hipEventSynchronize(bm->evBand[b]));
-        if (disp_pitch == Ws * sizeof(int16_t)) {
+        if ((size_t)width == Ws && disp_pitch == Ws * sizeof(int16_t)) {   // no pad columns between the rows: one copy per band
             memcpy((uint8_t*)disp + (size_t)y0 * disp_pitch, hD + (size_t)y0 * Ws, (size_t)(y1 - y0 - 1) * disp_pitch + (size_t)width * sizeof(int16_t));
         } else {
             for (int y = y0; y < y1; ++y)
                 memcpy((uint8_t*)disp + (size_t)y * disp_pitch, hD + (size_t)y * Ws, (size_t)width * sizeof(int16_t));
         }
     }
+    drain.armed = false;
     return RTDM_OK;
 }
 
@@ -774,6 +818,13 @@ int rtdm_bm_reset_stage_times(rtdm_bm* bm)
 }
 
 const char* rtdm_bm_search_variant(const rtdm_bm* bm) { return bm ? bm->variant.c_str() : ""; }
+int rtdm_bm_get_tuner_stats(const rtdm_bm* bm, long* shapes_measured, long* timing_launches)
+{
+    if (!bm) return RTDM_ERR_NULL;
+    if (shapes_measured) *shapes_measured = bm->tune_shapes;
+    if (timing_launches) *timing_launches = bm->tune_launches;
+    return RTDM_OK;
+}
 void rtdm_debug_search_kernel(int mode) { ring_set_mode(mode); }
 
 // ---- VideoFilterDevice ---------------------------------------------------------------------

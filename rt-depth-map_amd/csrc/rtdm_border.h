@@ -47,7 +47,9 @@ __device__ __forceinline__ int border_div_trunc(int num, int den)   // den > 0, 
 // monotone sample base: the w bytes come out of 8-byte spans of the staged row by v_perm with WAVE-UNIFORM selectors
 // (which only depend on where the clamp bites), so a row visit is ceil(w/4) x (LDS reads, 2 v_alignbyte, v_perm,
 // v_sad_u8 on 4 bytes) instead of w x (byte read, index clamp, single-byte SAD).
-template <int NCH>
+// LEGACY (stand-alone kernel only): rtdm_bm_params.legacy_right_clamp -- the sample base is clamped to W - rofs - 1 and
+// base + e addresses a plane of step W, so bytes past the row's end are the next row's first bytes (zeros after the last).
+template <int NCH, bool LEGACY = false>
 __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
                                             const BMGeom& g, const BorderGeom& bg, int bx, int by, int f)
 {
@@ -74,8 +76,9 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
     const uint8_t* Lb = Lp.base + (size_t)f * Lp.frame;
     const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
     const int j0 = x - r;                                              // first sample index
-    const int rbmin = min(max(g.rofs + j0, 0), W - D);
-    const int rbmax = min(max(g.rofs + j0 + w - 1, 0), W - D);
+    const int Wc = LEGACY ? W - g.rofs - 1 : W - D;                    // largest right sample base
+    const int rbmin = min(max(g.rofs + j0, 0), Wc);
+    const int rbmax = min(max(g.rofs + j0 + w - 1, 0), Wc);
     const int ra = rbmin & ~3, rsh = rbmin & 3;                        // rows are staged from the aligned byte ra on
     const int ndw = (w + 3) >> 2;                                      // window dwords (<= 6)
     const int stage_dw = (rsh + NCH * 64 + (rbmax - rbmin) + 12 + 3) >> 2;   // dwords staged per right row (<= rsp / 4)
@@ -85,13 +88,13 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
     unsigned sel[MAXQ], capm[MAXQ];
 #pragma unroll
     for (int q = 0; q < MAXQ; ++q) {
-        const int p0 = min(max(g.rofs + j0 + 4 * q, 0), W - D) - rbmin;
+        const int p0 = min(max(g.rofs + j0 + 4 * q, 0), Wc) - rbmin;
         aq[q] = p0 >> 2;
         unsigned sv = 0, cm = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int dx = 4 * q + k;
-            const int pk = min(max(g.rofs + j0 + dx, 0), W - D) - rbmin - 4 * aq[q];      // 0..7
+            const int pk = min(max(g.rofs + j0 + dx, 0), Wc) - rbmin - 4 * aq[q];         // 0..7
             sv |= (dx < w ? (unsigned)pk : 0x0cu) << (8 * k);                              // 0x0c selects the constant 0
             cm |= (dx < w ? (unsigned)g.cap : 0u) << (8 * k);
         }
@@ -129,8 +132,32 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
         for (int b = 0; b < RB; ++b) {
             const int row = ys0 - r + s0 + min(b, nb - 1);
             const uint32_t* rrow = (const uint32_t*)(Rb + (size_t)row * Rp.pitch + ra);    // plane pitches are multiples of 64
-            rv[b][0] = lane < stage_dw ? rrow[lane] : 0u;
-            rv[b][1] = lane + 64 < stage_dw ? rrow[lane + 64] : 0u;
+            if constexpr (LEGACY) {
+                // staged dword i = bytes ra + 4i .. ra + 4i + 3 of the row CONTINUED by the next row (a plane of step W)
+                const uint8_t* r0 = Rb + (size_t)row * Rp.pitch;
+                const uint8_t* r1 = Rb + (size_t)min(row + 1, g.H - 1) * Rp.pitch;
+                const bool more = row + 1 < g.H;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int i = lane + 64 * h, c0 = ra + 4 * i;
+                    uint32_t v = 0;
+                    if (i < stage_dw) {
+                        if (c0 + 3 < W) v = rrow[i];
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const int c = c0 + k;
+                                const uint32_t by = c < W ? r0[c] : (more && c - W < W) ? r1[c - W] : 0u;
+                                v |= by << (8 * k);
+                            }
+                        }
+                    }
+                    rv[b][h] = v;
+                }
+            } else {
+                rv[b][0] = lane < stage_dw ? rrow[lane] : 0u;
+                rv[b][1] = lane + 64 < stage_dw ? rrow[lane + 64] : 0u;
+            }
             lv[b] = lane < w ? Lb[(size_t)row * Lp.pitch + min(max(g.lofs + j0 + lane, 0), W - 1)] : (uint8_t)0;
         }
 #pragma unroll
@@ -229,12 +256,12 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
 }
 
 
-template <int NCH>
+template <int NCH, bool LEGACY>
 __global__ __launch_bounds__(256) void k_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost,
                                                        BMGeom g, BorderGeom bg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    border_body<NCH>(smem, Lp, Rp, disp, cost, g, bg, blockIdx.x, blockIdx.y, blockIdx.z);
+    border_body<NCH, LEGACY>(smem, Lp, Rp, disp, cost, g, bg, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 }  // namespace rtdm

@@ -4,8 +4,34 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 namespace rtdm {
+
+// Process-wide state shared BETWEEN handles (two handles may be driven from two host threads): environment switches are
+// read through env_int() into a function-local `static const` (C++11 initialises those exactly once, thread-safely), and
+// "once per device" actions go through OncePerDevice.  Nothing else in the launch paths is static and mutable.
+inline int env_int(const char* name, int dflt)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+// first(dev) is true for exactly one caller per device; the others may run concurrently with that caller's action, so the
+// action must be idempotent (hipFuncSetAttribute with a fixed value is).  Devices >= 64: always true.
+struct OncePerDevice {
+    std::atomic<unsigned long long> mask{0};
+    bool first()
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev < 0 || dev >= 64) return true;
+        const unsigned long long bit = 1ull << dev;
+        if (mask.load(std::memory_order_acquire) & bit) return false;
+        return !(mask.fetch_or(bit, std::memory_order_acq_rel) & bit);
+    }
+};
 
 // Geometry of one StereoBM search, derived once per call on the host.
 struct BMGeom {
@@ -23,6 +49,7 @@ struct BMGeom {
     int mask_cols;           // 1: the search kernel masks columns outside [vx0,vx1) itself
     int want_cost;           // 1: a cost plane is written for the left-right check
     int cost16;              // 1: the cost plane is uint16 (all SADs < 65536), else int32
+    int legacy;              // rtdm_bm_params.legacy_right_clamp: right sample base clamped to W-rofs-1, base + d wraps into the next row
 };
 
 struct Plane8 {  // batch of 8-bit images: frame f, row y at base + f*frame + y*pitch

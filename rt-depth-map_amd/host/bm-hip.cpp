@@ -14,11 +14,11 @@ static rtdm::Rect to_rect(const cv::Rect& r)
 
 HIPMatcher::HIPMatcher(cv::Rect& roi1, cv::Rect& roi2, int preFilterCap, int blockSize, int minDisparity,
 		int textureThreshold, int numOfDisparities, int maxDisparity, int uniquenessRatio, int speckleWindowSize,
-		int speckleRange, int disp12MaxDiff, int width, int height, int device)
+		int speckleRange, int disp12MaxDiff, int width, int height, int device, bool legacyRightClamp)
 {
 	core = new rtdm::HIPMatcherCore(to_rect(roi1), to_rect(roi2), preFilterCap, blockSize, minDisparity,
 			textureThreshold, numOfDisparities, maxDisparity, uniquenessRatio, speckleWindowSize, speckleRange,
-			disp12MaxDiff, width, height, 1, device);
+			disp12MaxDiff, width, height, 1, device, legacyRightClamp);
 }
 
 HIPMatcher::~HIPMatcher()

@@ -18,7 +18,7 @@ class HIPMatcher : public BlockMatcher
 public:
 	HIPMatcher(cv::Rect& roi1, cv::Rect& roi2, int preFilterCap, int blockSize, int minDisparity,
 			int textureThreshold, int numOfDisparities, int maxDisparity, int uniquenessRatio, int speckleWindowSize,
-			int speckleRange, int disp12MaxDiff, int width, int height, int device = 0);
+			int speckleRange, int disp12MaxDiff, int width, int height, int device = 0, bool legacyRightClamp = false);
 	~HIPMatcher();
 	void setROI1(cv::Rect roi1);
 	void setROI2(cv::Rect roi2);

@@ -7,7 +7,7 @@ namespace rtdm {
 HIPMatcherCore::HIPMatcherCore(const Rect& roi1, const Rect& roi2, int preFilterCap, int blockSize, int minDisparity,
                                int textureThreshold, int numOfDisparities, int maxDisparity, int uniquenessRatio,
                                int speckleWindowSize, int speckleRange, int disp12MaxDiff,
-                               int maxWidth, int maxHeight, int maxBatch, int device)
+                               int maxWidth, int maxHeight, int maxBatch, int device, bool legacyRightClamp)
 {
     (void)roi1; (void)roi2; (void)maxDisparity;   // ignored by the reference constructor as well (bm-sw.cpp:12-26)
     params_.preFilterCap = preFilterCap;
@@ -19,6 +19,7 @@ HIPMatcherCore::HIPMatcherCore(const Rect& roi1, const Rect& roi2, int preFilter
     params_.speckleWindowSize = speckleWindowSize;
     params_.speckleRange = speckleRange;
     params_.disp12MaxDiff = disp12MaxDiff;
+    params_.legacy_right_clamp = legacyRightClamp ? 1 : 0;
     status_ = rtdm_bm_create(&params_, maxWidth, maxHeight, maxBatch, device, &bm_);
     if (status_ != RTDM_OK)
         std::fprintf(stderr, "HIPMatcher: %s%s%s\n", rtdm_strerror(status_),

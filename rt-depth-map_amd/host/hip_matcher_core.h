@@ -25,7 +25,9 @@ public:
     HIPMatcherCore(const Rect& roi1, const Rect& roi2, int preFilterCap, int blockSize, int minDisparity,
                    int textureThreshold, int numOfDisparities, int maxDisparity, int uniquenessRatio,
                    int speckleWindowSize, int speckleRange, int disp12MaxDiff,
-                   int maxWidth, int maxHeight, int maxBatch = 1, int device = 0);
+                   int maxWidth, int maxHeight, int maxBatch = 1, int device = 0, bool legacyRightClamp = false);
+    // legacyRightClamp: rtdm_bm_params.legacy_right_clamp -- the right-border sampling rule of OpenCV 3.1-3.2, the era
+    // the reference links (Makefile.include:18-23); the default is the 4.x rule.
     ~HIPMatcherCore();
     HIPMatcherCore(const HIPMatcherCore&) = delete;
     HIPMatcherCore& operator=(const HIPMatcherCore&) = delete;

@@ -17,11 +17,11 @@ from . import binding as B
 class HIPMatcher:
     def __init__(self, roi1=None, roi2=None, preFilterCap=31, blockSize=13, minDisparity=0, textureThreshold=10,
                  numOfDisparities=64, maxDisparity=None, uniquenessRatio=10, speckleWindowSize=100,
-                 speckleRange=32, disp12MaxDiff=1, width=1280, height=720, max_batch=1, device=0):
+                 speckleRange=32, disp12MaxDiff=1, width=1280, height=720, max_batch=1, device=0, legacy_right_clamp=0):
         # roi1/roi2/maxDisparity are accepted and ignored, exactly like bm-sw.cpp:12-26
         self._h = C.c_void_p()
         self.params = B.make_params(preFilterCap, blockSize, minDisparity, numOfDisparities, textureThreshold,
-                                    uniquenessRatio, speckleWindowSize, speckleRange, disp12MaxDiff)
+                                    uniquenessRatio, speckleWindowSize, speckleRange, disp12MaxDiff, legacy_right_clamp)
         self.width, self.height, self.max_batch, self.device = width, height, max_batch, device
         B.check(B.lib().rtdm_bm_create(C.byref(self.params), width, height, max_batch, device, C.byref(self._h)),
                 "rtdm_bm_create")
@@ -76,14 +76,22 @@ class HIPMatcher:
         return (mean, cnt, disp) if want_disp else (mean, cnt)
 
     def compute_batch(self, left, right, out=None):
-        """left/right: uint8 [n, H, W] C-contiguous host arrays -> int16 [n, H, W] (out: a C-contiguous int16 [n, H, W]
-        array to write into).  Page-locked arrays (hipHostMalloc / torch pin_memory) move by DMA beside the compute."""
-        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        """left/right: uint8 [n, H, W] host arrays (frame and row strides free, column stride 1: views of wider planes are
+        passed as they are) -> int16 [n, H, W] (out: an int16 [n, H, W] array, column stride 2 bytes, to write into).
+        Page-locked arrays (hipHostMalloc / torch pin_memory) move by DMA beside the compute."""
+        def plane(a):
+            a = np.asarray(a)
+            ok = a.dtype == np.uint8 and a.ndim == 3 and a.strides[2] == 1 and a.strides[1] >= a.shape[2] and a.strides[0] >= 0
+            return a if ok else np.ascontiguousarray(a, np.uint8)
+        left, right = plane(left), plane(right)
+        if left.strides != right.strides:
+            left, right = np.ascontiguousarray(left), np.ascontiguousarray(right)
         n, H, W = left.shape
+        assert right.shape == left.shape
         disp = np.empty((n, H, W), np.int16) if out is None else out
-        assert disp.dtype == np.int16 and disp.shape == (n, H, W) and disp.flags.c_contiguous
-        B.check(B.lib().rtdm_bm_compute_batch(self._h, n, left.ctypes.data, right.ctypes.data, W, W * H, W, H,
-                                              disp.ctypes.data, W * 2, W * H * 2), "rtdm_bm_compute_batch")
+        assert disp.dtype == np.int16 and disp.shape == (n, H, W) and disp.strides[2] == 2 and disp.strides[1] >= W * 2
+        B.check(B.lib().rtdm_bm_compute_batch(self._h, n, left.ctypes.data, right.ctypes.data, left.strides[1], left.strides[0], W, H,
+                                              disp.ctypes.data, disp.strides[1], disp.strides[0]), "rtdm_bm_compute_batch")
         return disp
 
     def compute_device(self, d_left, d_right, d_disp, stream=None):
@@ -114,6 +122,12 @@ class HIPMatcher:
     @property
     def search_variant(self):
         return B.lib().rtdm_bm_search_variant(self._h).decode()
+
+    def tuner_stats(self):
+        """(batch shapes whose strip count was measured, extra search launches that took) -- rtdm_bm_get_tuner_stats."""
+        a, b = C.c_long(), C.c_long()
+        B.check(B.lib().rtdm_bm_get_tuner_stats(self._h, C.byref(a), C.byref(b)), "rtdm_bm_get_tuner_stats")
+        return a.value, b.value
 
 
 class HIPSemiGlobalMatcher:

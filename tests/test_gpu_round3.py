@@ -1,0 +1,207 @@
+"""GPU suite, round-3 additions (-m gpu).  Everything goes through the C ABI and is compared bit for bit with the CPU
+oracle (parity unpinned against OpenCV itself: oracle/rtdm_oracle.h)."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import load, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu suite needs an MI355X"
+    return load()
+
+
+def assert_same(got, want):
+    if not np.array_equal(got, want):
+        bad = np.argwhere(got != want)
+        raise AssertionError("%d / %d pixels differ; first at (y,x)=%s got %d want %d" % (
+            len(bad), got.size, tuple(bad[0]), got[tuple(bad[0])], want[tuple(bad[0])]))
+
+
+# ---- guard bands: a view's pad columns belong to the caller (estimator.cpp:33,36 passes views) ------------------------
+# The internal disparity plane has rows of Ws = width rounded up to 8; a caller whose pitch happens to equal Ws * 2 must
+# still only see its `width` columns written.
+def test_pageable_view_whose_pitch_equals_the_internal_pitch_keeps_its_pad_columns(pkg, oracle, synth):
+    W, H, D, w = 233, 156, 32, 7                                # 233 -> Ws = 240
+    Lf, Rf = synth.make_pair(synth.STREAM_SEED + 7, 240, H, D)
+    L, R = Lf[:, :W], Rf[:, :W]                                 # views at x = 0 of 240-wide planes
+    plane = np.full((H, 240), 777, np.int16)
+    O = plane[:, :W]                                            # pitch 480 == Ws * 2
+    assert O.strides[0] == 480
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H)
+    m.compute(L, R, O)
+    m.close()
+    assert_same(O, oracle.bm_compute(np.ascontiguousarray(L), np.ascontiguousarray(R), numDisparities=D, blockSize=w))
+    assert (plane[:, W:] == 777).all()                          # columns [233, 240) untouched
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_batch_with_240_wide_buffers_at_width_233_keeps_its_pad_columns(pkg, oracle, synth, pinned):
+    import torch
+    n, W, H, D, w = 5, 233, 120, 32, 7
+    Lf, Rf = synth.make_stream(91, n, 240, H, D)
+    planes = torch.full((n, H, 240), 777, dtype=torch.int16)
+    if pinned:
+        Lt, Rt, planes = torch.from_numpy(Lf).pin_memory(), torch.from_numpy(Rf).pin_memory(), planes.pin_memory()
+        Lf, Rf = Lt.numpy(), Rt.numpy()
+    out = planes.numpy()
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=4)
+    m.compute_batch(Lf[:, :, :W], Rf[:, :, :W], out[:, :, :W])
+    m.close()
+    for i in range(n):
+        assert_same(out[i, :, :W], oracle.bm_compute(np.ascontiguousarray(Lf[i, :, :W]), np.ascontiguousarray(Rf[i, :, :W]),
+                                                     numDisparities=D, blockSize=w))
+    assert (out[:, :, W:] == 777).all()
+
+
+# ---- rtdm_bm_params.legacy_right_clamp: the right-border rule of the reference's OpenCV era (oracle hazard H1) ----------
+# Compared with the oracle's own legacy switch (oracle/bm_oracle.c: rbase clamp W-rofs-1, a plane of step W, zeros after
+# the last row).  Still parity-unpinned: the switch restates the 3.x source from memory, no OpenCV here to run.
+def _legacy_case(rng):
+    D = int(rng.choice([16, 32, 48, 64, 96, 128, 192, 256]))
+    w = int(rng.choice([5, 7, 9, 11, 13, 15, 21, 25]))          # 25: the generic kernel; 21: the border kernel beside k_search_fast
+    minD = int(rng.choice([0, 0, 0, 3, -7]))
+    W = int(rng.integers(D + abs(minD) + w + 20, D + abs(minD) + w + 200))
+    H = int(rng.integers(w + 3, w + 60))
+    kw = dict(numDisparities=D, blockSize=w, minDisparity=minD, preFilterCap=int(rng.choice([31, 31, 15])),
+              textureThreshold=int(rng.choice([10, 0])), uniquenessRatio=int(rng.choice([10, 0, 15])),
+              speckleWindowSize=int(rng.choice([100, 0])), speckleRange=32, disp12MaxDiff=int(rng.choice([1, 1, -1, 0, 3])))
+    return W, H, kw
+
+
+def _hip_kw(kw):
+    k = dict(kw)
+    k["numOfDisparities"] = k.pop("numDisparities")
+    return k
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_legacy_right_clamp_matches_the_oracles_legacy_switch(pkg, oracle, synth, seed):
+    rng = np.random.default_rng(3000 + seed)
+    W, H, kw = _legacy_case(rng)
+    L, R = synth.make_pair(synth.STREAM_SEED + 11000 + seed, W, H, kw["numDisparities"])
+    if seed % 4 == 0:                       # pitched views: the device must wrap at W, not at its own pitch
+        pl, pr = np.zeros((H + 2, W + 29), np.uint8), np.zeros((H + 2, W + 29), np.uint8)
+        pl[1:1 + H, 3:3 + W] = L; pr[1:1 + H, 3:3 + W] = R
+        L, R = pl[1:1 + H, 3:3 + W], pr[1:1 + H, 3:3 + W]
+    base = oracle.bm_compute(L, R, **kw)
+    oracle.set_legacy_right_clamp(True)
+    try:
+        want = oracle.bm_compute(L, R, **kw)
+    finally:
+        oracle.set_legacy_right_clamp(False)
+    m = pkg.HIPMatcher(width=W, height=H, legacy_right_clamp=1, **_hip_kw(kw))
+    got = m.compute(L, R)
+    variant = m.search_variant
+    m.close()
+    assert_same(got, want)
+    m0 = pkg.HIPMatcher(width=W, height=H, **_hip_kw(kw))               # the default stays the 4.x rule
+    assert_same(m0.compute(L, R), base)
+    m0.close()
+    assert variant
+
+
+def test_legacy_right_clamp_is_live_and_confined_on_the_golden_shape(pkg, oracle, synth):
+    # the shape of tests/test_oracle_bm.py::test_right_clamp_hazard_is_confined, batched through the device entry point
+    import torch
+    n, W, H, D, w = 20, 320, 240, 32, 9
+    Ls, Rs = synth.make_stream(55, n, W, H, D)
+    dL, dR = torch.from_numpy(Ls).cuda(), torch.from_numpy(Rs).cuda()
+    outs = {}
+    for flag in (0, 1):
+        m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n, legacy_right_clamp=flag)
+        dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+        m.compute_device(dL, dR, dD, torch.cuda.current_stream().cuda_stream)      # n >= 16: border kernel on the side stream
+        torch.cuda.synchronize()
+        outs[flag] = dD.cpu().numpy()
+        m.close()
+    oracle.set_legacy_right_clamp(True)
+    try:
+        for i in (0, 7, n - 1):
+            assert_same(outs[1][i], oracle.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w))
+    finally:
+        oracle.set_legacy_right_clamp(False)
+    for i in (0, 7, n - 1):
+        assert_same(outs[0][i], oracle.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w))
+    diff = outs[0] != outs[1]
+    assert not diff[:, :, :W - w // 2 - D - 1].any()                   # H1: only votes near the right edge can differ
+
+
+def test_legacy_right_clamp_value_is_validated(pkg):
+    from importlib import import_module
+    B = import_module("rt-depth-map_amd.binding")
+    with pytest.raises(B.RtdmError) as e:
+        pkg.HIPMatcher(numOfDisparities=32, blockSize=9, width=128, height=64, legacy_right_clamp=2)
+    assert e.value.status == -1
+
+
+# ---- the strip-count tuner is keyed on the SHAPE of the work: counted, not timed -------------------------------------
+def test_roi_moving_batched_caller_never_triggers_the_tuner(pkg, synth):
+    import torch
+    n, W, H, D = 16, 640, 480, 64
+    dL = torch.empty((n, H, W), dtype=torch.uint8, device="cuda"); dR = torch.empty_like(dL)
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    pkg.synth_pairs_device(dL, dR, first_frame=0, numDisparities=D, stream=st)
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=9, width=W, height=H, max_batch=n)
+    for k in range(50):                      # 50 distinct ROI sizes: every shape is seen once, none is measured
+        m.setROI1((80 + k, 40 + (k % 7), 200 + 5 * k, 150 + 3 * k))
+        m.compute_device(dL, dR, dD, st)
+    torch.cuda.synchronize()
+    assert m.tuner_stats() == (0, 0)
+    for k in range(6):                       # one size at six positions: ONE shape, measured once (on its second sighting)
+        m.setROI1((140 + 11 * k, 30 + 5 * k, 300, 200))         # (far enough from the borders that nothing is clipped)
+        m.compute_device(dL, dR, dD, st)
+    torch.cuda.synchronize()
+    shapes, launches = m.tuner_stats()
+    assert shapes == 1 and 0 < launches <= 30
+    m.setROI1((0, 0, 0, 0))
+    for _ in range(3):
+        m.compute_device(dL, dR, dD, st)
+    torch.cuda.synchronize()
+    assert m.tuner_stats()[0] == 2           # the full frame is a second shape
+    m.close()
+
+
+# ---- two handles driven from two host threads (process-wide state is atomics / once-flags only) ------------------------
+def test_two_handles_on_two_threads_give_the_single_thread_bytes(pkg, oracle, synth):
+    import torch
+    cfgs = [(400, 150, 64, 9, 22), (333, 120, 128, 11, 18)]      # both take k_search_ring forms that raise their LDS limit
+    want, errs, got = {}, [], {}
+
+    def run(k):
+        try:
+            W, H, D, w, n = cfgs[k]
+            Ls, Rs = synth.make_stream(400 + k, n, W, H, D)
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                dL, dR = torch.from_numpy(Ls).cuda(), torch.from_numpy(Rs).cuda()
+                dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+                m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n)
+                for _ in range(4):
+                    m.compute_device(dL, dR, dD, s.cuda_stream)
+                s.synchronize()
+                one = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H)
+                h = one.compute(Ls[0], Rs[0])
+                one.close()
+                got[k] = (dD.cpu().numpy(), h, Ls, Rs)
+                m.close()
+        except Exception as e:              # noqa: BLE001 -- reported by the main thread
+            errs.append((k, repr(e)))
+
+    ts = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errs, errs
+    for k, (W, H, D, w, n) in enumerate(cfgs):
+        out, h, Ls, Rs = got[k]
+        for i in (0, n - 1):
+            assert_same(out[i], oracle.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w))
+        assert_same(h, out[0])
