@@ -13,6 +13,7 @@ path.  Two modes:
 One process per GPU; nothing here touches the compute path itself (`compute` is a callable).
 """
 import contextlib
+import time
 
 import torch
 
@@ -42,11 +43,11 @@ class _Streams:
     def on_comm(self):
         return torch.cuda.stream(self.comm) if self.cuda else contextlib.nullcontext()
 
-    def mark(self, comm=False):
-        """An event at the current tail of `main` (or `comm`); None on CPU."""
+    def mark(self, comm=False, timing=False):
+        """An event at the current tail of `main` (or `comm`); None on CPU (timing: the host clock there)."""
         if not self.cuda:
-            return None
-        ev = torch.cuda.Event()
+            return time.perf_counter() if timing else None
+        ev = torch.cuda.Event(enable_timing=timing)
         ev.record(self.comm if comm else self.main)
         return ev
 
@@ -63,8 +64,27 @@ class _Streams:
             self.main.wait_stream(self.comm)
 
 
+def new_timings():
+    """Collector for scatter_compute_gather(timings=...): per-chunk (begin, end) marks of the three phases."""
+    return {"scatter": [], "compute": [], "gather": []}
+
+
+def phase_ms(timings):
+    """Milliseconds per phase, summed over the chunks of one pass (call after the device has been synchronised): HIP-event
+    intervals on the stream the phase was issued from -- scatter and gather on the side stream, compute on the caller's -- or
+    host clock differences on a CPU device, where every phase blocks."""
+    out = {}
+    for k, marks in timings.items():
+        tot = 0.0
+        for a, b in marks:
+            tot += a.elapsed_time(b) if hasattr(a, "elapsed_time") else (b - a) * 1e3
+        out[k + "_ms"] = round(tot, 3)
+    out["chunks"] = len(timings["compute"])
+    return out
+
+
 def scatter_compute_gather(dist, left, right, n_frames, frame_shape, compute, device, out_dtype=torch.int16,
-                           chunk=None, compute_into=None):
+                           chunk=None, compute_into=None, timings=None):
     """left/right: uint8 [n_frames, H, W] on rank 0 (ignored elsewhere).  Returns the gathered
     [n_frames, H, W] disparities on rank 0 (None elsewhere).  `compute(L, R) -> D` runs on this rank's
     shard (tensors on `device`); `compute_into(L, R, out)`, if given, is used instead and writes `out`.
@@ -74,7 +94,11 @@ def scatter_compute_gather(dist, left, right, n_frames, frame_shape, compute, de
     stream (collectives are issued asynchronously from it; their completion is joined to the compute
     stream with Work.wait(), which does not block the host on a GPU).  The root passes VIEWS of its frames
     to the scatter and views of the result to the gather; only a ragged last chunk (a rank whose block is
-    one frame shorter) goes through a padded temporary."""
+    one frame shorter) goes through a padded temporary.
+
+    timings (new_timings()): every phase of every chunk is bracketed by marks on the stream it is issued from.  The end mark
+    of a collective needs the issuing stream to wait for it (Work.wait()), which serialises the side stream's collectives --
+    they are in order on RCCL's own stream anyway -- so a timed pass is for diagnosis, not for the throughput figure."""
     world, rank = dist.get_world_size(), dist.get_rank()
     H, W = frame_shape
     counts = shard_sizes(n_frames, world)
@@ -116,8 +140,14 @@ def scatter_compute_gather(dist, left, right, n_frames, frame_shape, compute, de
             st.comm_waits(in_free[b])
             ls = src_views(left, c0, c1) if rank == 0 else None
             rs = src_views(right, c0, c1) if rank == 0 else None
-            return (dist.scatter(lbuf[b][:m], ls, src=0, async_op=True),
-                    dist.scatter(rbuf[b][:m], rs, src=0, async_op=True))
+            t_a = st.mark(comm=True, timing=True) if timings is not None else None
+            wks = (dist.scatter(lbuf[b][:m], ls, src=0, async_op=True),
+                   dist.scatter(rbuf[b][:m], rs, src=0, async_op=True))
+            if timings is not None:
+                for wk in wks:
+                    wk.wait()
+                timings["scatter"].append((t_a, st.mark(comm=True, timing=True)))
+            return wks
 
     def issue_gather(k, done):
         b, (c0, c1) = k % NB, chunks[k]
@@ -136,8 +166,12 @@ def scatter_compute_gather(dist, left, right, n_frames, frame_shape, compute, de
                         dst.append(t); fix.append((t, starts[r] + lo, hi - lo))
                 keep.extend(dst)
             # collectives move raw bytes: gloo has no int16 kernels, and the payload is opaque anyway
+            t_a = st.mark(comm=True, timing=True) if timings is not None else None
             wk = dist.gather(obuf[b][:m].view(torch.uint8),
                              [d.view(torch.uint8) for d in dst] if rank == 0 else None, dst=0, async_op=True)
+            if timings is not None:
+                wk.wait()
+                timings["gather"].append((t_a, st.mark(comm=True, timing=True)))
             if fix:
                 wk.wait()                              # comm stream waits (host too on CPU); then the ragged tails
                 for t, s0, cnt in fix:
@@ -154,11 +188,14 @@ def scatter_compute_gather(dist, left, right, n_frames, frame_shape, compute, de
         if out_busy[b] is not None:
             out_busy[b].wait()                         # obuf[b] is free again (gather of chunk k-2)
         live = max(0, min(c1, mine) - c0)
+        t_a = st.mark(timing=True) if timings is not None else None
         if live > 0:
             if compute_into is not None:
                 compute_into(lbuf[b][:live], rbuf[b][:live], obuf[b][:live])
             else:
                 obuf[b][:live] = compute(lbuf[b][:live], rbuf[b][:live])
+        if timings is not None:
+            timings["compute"].append((t_a, st.mark(timing=True)))
         done = st.mark()
         in_free[b] = done
         out_busy[b] = issue_gather(k, done)
