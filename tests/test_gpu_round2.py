@@ -91,33 +91,15 @@ def test_bench_gpus2_launches_two_ranks_itself():
     env = {"RTDM_DIST_BACKEND": "gloo"}
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         os.environ.pop(k, None)
-    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "16", "--no-cpu-baseline"], env=env)
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "16", "--no-cpu-baseline", "--no-configs"], env=env)
     assert out["n_gpus"] == 2 and out["parity_ok"] is True and out["parity_checked_frames"] == 6
     # config 4 through the same launcher, two ranks
     out = _bench(["--gpus", "2", "--rccl-stream", "10", "--chunk", "2", "--steps", "1", "--warmup", "1"], env=env)
     assert out["n_gpus"] == 2 and out["parity_ok"] is True and out["equals_direct_call"] is True
 
 
-# ---- a batched caller that moves its ROI every call (estimator.cpp:53-54) never stalls on the autotuner --------------
-def test_roi_moving_batched_caller_keeps_flat_call_time(pkg, synth):
-    import torch
-    n, W, H, D = 16, 640, 480, 64
-    dL = torch.empty((n, H, W), dtype=torch.uint8, device="cuda"); dR = torch.empty_like(dL)
-    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    pkg.synth_pairs_device(dL, dR, first_frame=0, numDisparities=D, stream=st)
-    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=9, width=W, height=H, max_batch=n)
-    times = []
-    for k in range(50):                      # 50 distinct ROI sizes and positions
-        m.setROI1((80 + k, 40 + (k % 7), 200 + 5 * k, 150 + 3 * k))
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        m.compute_device(dL, dR, dD, st)
-        torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
-    t = np.array(times[2:])
-    # a tuning pass is ~30 extra launches and shows up as a >10x outlier -- for every new ROI if the table were keyed on
-    # positions; growth with the ROI area is < 4x over the run.  (Two stray outliers are allowed: a shared box hiccups.)
-    assert int((t > 6 * np.median(t)).sum()) <= 2, times
-    m.close()
+# (the autotuner's cost for a caller that moves its ROI is asserted on the tuner's own counters now:
+#  tests/test_gpu_round3.py::test_roi_moving_batched_caller_never_triggers_the_tuner)
 
 
 # ---- the opt-in two-lane mode (RTDM_LANES=2): pieces on two workspace slices, row kernels on a back stream ------------

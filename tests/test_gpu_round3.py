@@ -205,3 +205,60 @@ def test_two_handles_on_two_threads_give_the_single_thread_bytes(pkg, oracle, sy
         for i in (0, n - 1):
             assert_same(out[i], oracle.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w))
         assert_same(h, out[0])
+
+
+# ---- bench.py's own line: every north_star size with parity, and the evidence kept at N > 1 ---------------------------
+def _bench(args, env=None, timeout=900):
+    import json, subprocess, sys
+    e = dict(os.environ)
+    e.update(env or {})
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=e, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_line_carries_every_north_star_size_with_parity():
+    out = _bench(["--steps", "3", "--warmup", "2", "--batch", "64"])
+    assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["steps"] == 3 and out["parity_ok"] is True
+    keys = [c["key"] for c in out["configs"]]
+    assert keys == ["config1", "config2", "config3", "reference_default"]
+    for c in out["configs"]:
+        assert c["parity_ok"] is True and c["steps"] >= 20 and c["pairs_per_s"] > 0 and c["cpu_pairs_per_s"] > 0
+        assert 0 < c["frac_of_hbm"] < 1 and c["search_kernel"].startswith("fast")
+    assert out["configs"][2]["morph_parity_ok"] is True
+    assert out["sustained"]["seconds"] >= 1.5
+    assert out["roofline"]["qsad_issue_floor"]["frac_of_floor"] < 1.0
+    cb = out["cpu_baseline"]
+    assert cb["mode"] in ("frames", "rows") and cb["cores"] == cb["threads"] and cb["value"] > 0
+    ref = out["single_frame"]["reference_call"]
+    assert ref["parity_ok"] is True and out["single_frame"]["same_as_batched"] is True
+
+
+def test_bench_two_ranks_keep_cpu_baseline_and_roofline():
+    # gloo: both ranks share this GPU; the N > 1 line must be as complete as the N = 1 line
+    out = _bench(["--gpus", "2", "--steps", "2", "--warmup", "2", "--batch", "16", "--no-configs"], env={"RTDM_DIST_BACKEND": "gloo"})
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["parity_ok"] is True and out["parity_checked_frames"] == 6
+    assert out["cpu_baseline"] is not None and out["cpu_baseline"]["value"] > 0
+    assert out["roofline"]["achieved"] > 0
+
+
+def test_two_gpus_over_rccl_when_the_box_has_them():
+    """Multi-rank RCCL execution: runs only where torch sees >= 2 GPUs (the driver's 8-GPU node); a one-GPU box skips.  No
+    scaling curve is produced or simulated here."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs: multi-rank RCCL is unmeasured on a one-GPU box")
+    env = {"RTDM_DIST_BACKEND": "nccl"}
+    out = _bench(["--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "64", "--no-configs"], env=env)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["parity_ok"] is True
+    assert out["cpu_baseline"] is not None
+    out = _bench(["--gpus", "2", "--rccl-stream", "64", "--chunk", "8", "--steps", "2", "--warmup", "1"], env=env)
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["backend"] == "nccl"
+    assert out["parity_ok"] is True and out["equals_direct_call"] is True
+    ph = out["phase_ms_per_pass"]
+    assert ph["chunks"] == 4 and ph["scatter_ms"] > 0 and ph["compute_ms"] > 0 and ph["gather_ms"] > 0

@@ -34,7 +34,13 @@ def _worker(rank, world, port, chunk, q):
     if rank == 0:
         L, R = pkg.synth.make_stream(0, NF, W, H, D)
         left, right = torch.from_numpy(L), torch.from_numpy(R)
-    out = sh.scatter_compute_gather(dist, left, right, NF, (H, W), _oracle_compute, torch.device("cpu"), chunk=chunk)
+    tm = sh.new_timings() if chunk == 2 else None
+    out = sh.scatter_compute_gather(dist, left, right, NF, (H, W), _oracle_compute, torch.device("cpu"), chunk=chunk, timings=tm)
+    if tm is not None:                       # per-phase marks: one triple per chunk, host clock on a CPU device
+        ph = sh.phase_ms(tm)
+        nchunks = -(-max(sh.shard_sizes(NF, world)) // chunk)
+        assert ph["chunks"] == nchunks and len(tm["scatter"]) == nchunks and len(tm["gather"]) == nchunks
+        assert ph["compute_ms"] > 0 and ph["scatter_ms"] >= 0 and ph["gather_ms"] >= 0
     # comm-free mode: every rank makes its own frames; rank 0 checks its block against the stream
     first, cnt = sh.local_stream(0, NF, world, rank)
     Lr, Rr = pkg.synth.make_stream(first, cnt, W, H, D)
