@@ -9,6 +9,10 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librtdm_hip.so")
+# RTDM_LIB_VARIANT=NAME: a diagnostic / experimental build made by `make variant NAME=...` (lib/variants/); the shipped
+# library is never rebuilt in place for an experiment
+if os.environ.get("RTDM_LIB_VARIANT"):
+    LIB_PATH = os.path.join(_HERE, "lib", "variants", "librtdm_hip_%s.so" % os.environ["RTDM_LIB_VARIANT"])
 
 RTDM_OK = 0
 STATUS = {0: "RTDM_OK", -1: "RTDM_ERR_BAD_PARAM", -2: "RTDM_ERR_BAD_SIZE", -3: "RTDM_ERR_NO_DEVICE",

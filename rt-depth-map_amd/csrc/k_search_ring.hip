@@ -48,6 +48,9 @@
 #ifndef RING_LDS_SELECT   // 1: select_disparity_lds (fetches through LDS), 0: select_disparity (v_cndmask tree)
 #define RING_LDS_SELECT 1
 #endif
+#ifndef RING_MINREC       // 0: GroupSelect (lane reductions) also where GroupSelectRec (minima in the owner's record) applies: A/B
+#define RING_MINREC 1
+#endif
 #ifndef RING_SPLIT_SELECT // 1: GroupSelect also for the two-lane configurations that default to the transposing selection
 #define RING_SPLIT_SELECT 0 // (D = 16, D = 32 except w = 9: measured 0-8 % slower there, profiles/r02_ring_split_select_ab.txt;
 #endif                      //  tools/ring_split_ab.sh)
@@ -249,6 +252,11 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][PPW] (the lanes of a pixel write the same value)
     uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;       // this lane's selection record
     uint32_t* scr_w = stg + C::STG + p * SelRecord<D>::DWORDS + h * NRL;   // SPLIT: where this lane's slice of the group's first row goes
+    // D <= 64: the group minima live in the owner's record too and nothing crosses between the lanes (GroupSelectRec)
+    constexpr bool MINREC = SPLIT && D <= 64 && RING_MINREC;
+    using GSel = std::conditional_t<MINREC, GroupSelectRec<D, LPP>, GroupSelect<D, LPP>>;
+    unsigned short* scr_m = (unsigned short*)(stg + C::STG + p * SelRecord<D>::DWORDS + D / 2) + h * (NRL / 4);   // ... and the minima of its groups
+    if constexpr (MINREC) GroupSelectRec<D, LPP>::init(scr);
 
     // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
     // Unconditional loads: bytes past a row's end only ever reach lanes that are not `active`, and the prefiltered planes
@@ -376,7 +384,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             const int t = t0 + U;
             if (t >= nstepsg) return false;
             RING_STAMP(0);                                          // (loop overhead + whatever precedes the group)
-            GroupSelect<D, LPP> gsel;
+            GSel gsel;
             int tsum = 0;
             ring_for_rows(std::make_integer_sequence<int, LPP>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
@@ -390,7 +398,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
                 if constexpr (SPLIT && RING_ABL == 0) {
                     // the row's slice goes to its owner's record and into the group minima at once: S[R] is dead after this
                     // (also while the window fills: a branch around it turns into selects on all of gsel's state)
-                    gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), (uint32_t)(h * (NRL / 4)));
+                    if constexpr (MINREC) gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), scr_m + R * (PPW * SelRecord<D>::DWORDS * 2));
+                    else gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), (uint32_t)(h * (NRL / 4)));
                 }
             });
             if (t + LPP - 1 < WS - 1) return true;                  // the window is still filling
@@ -474,10 +483,14 @@ static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g
 // registers per lane leaves room for two waves per SIMD.  Four lanes per pixel: the D = 64 ones, whose two-lane ring holds
 // them at two waves, and D = 96 (D = 32 with four lanes measured 0-8 % slower than with two: not instantiated).  Eight
 // lanes: D = 128.
+#ifdef RTDM_RING_DEV      // development builds (tools/ring_isa.sh): the headline instantiation only
+#define RTDM_RING_TABLE(X) X(64, 9, 4)
+#else
 #define RTDM_RING_TABLE(X) X(64, 9, 2) X(64, 7, 2) X(64, 5, 2) X(32, 7, 2) X(32, 9, 2) X(32, 11, 2) X(32, 13, 2) X(48, 7, 2) X(48, 9, 2) \
                            X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4) X(64, 11, 4) X(64, 13, 4) \
                            X(128, 7, 8) X(128, 9, 8) X(128, 11, 8) X(128, 13, 8) X(96, 7, 4) X(96, 9, 4) X(96, 11, 4) X(96, 13, 4) X(48, 11, 2) X(48, 13, 2) \
                            X(16, 11, 2) X(16, 13, 2) X(32, 5, 2) X(32, 15, 2) X(48, 5, 2) X(64, 15, 4) X(128, 15, 8)
+#endif
 
 // rtdm_debug_search_kernel (a process-wide A/B switch; one atomic word so that a launch on another thread sees a consistent
 // pair): low byte = mode + 1 (0 never, 1 wherever instantiated, -1 default), next byte = lanes per pixel to force (0: none)

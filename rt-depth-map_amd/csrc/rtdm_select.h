@@ -417,4 +417,119 @@ struct GroupSelect {
     }
 };
 
+// GroupSelectRec: GroupSelect with the group minima kept in the OWNER's record as well (D <= 64: the D/8 packed u16 minima
+// are D/16 <= 4 dwords and live in the four padding dwords behind the D/2 SAD dwords).  A lane's part of a row shrinks to
+// the packed minima of its groups (3 v_pk_min + one SDWA minimum per group, written with ds_write_b16) and NOTHING crosses
+// between the lanes any more: the owner reads the minima of all D/8 groups back with one 16-byte read and builds the keys
+// (v_perm, v_min3: 12 instructions at D = 64 against 16 per-row key instructions + an 8-instruction lane reduction), and
+// evaluates test (A) itself as a second sum identity over those minima (8 packed instructions against a 9-instruction
+// broadcast of T+1, 16 compares in the other lanes and a 10-instruction reduction).  Per 64 pixel-rows at D = 64, four lanes per pixel: about 45 VALU instructions
+// and 12 registers of per-group state (mm, kpart) less.  Same results: the tests (A) and (B) of GroupSelect, same values.
+template <int D, int LPP>
+struct GroupSelectRec {
+    static constexpr int NRL = D / (2 * LPP), NGH = NRL / 4, NG = D / 8, NGD = (NG + 1) / 2;
+    static_assert(D == 16 || D == 32 || D == 48 || D == 64, "the minima must fit the record's four padding dwords");
+    static_assert(NRL % 4 == 0, "a lane's slice must be whole groups of eight disparities");
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+    // once per kernel: unused minima slots of this lane's record never win and never count
+    static __device__ __forceinline__ void init(uint32_t* rec_own)
+    { *(u4*)(rec_own + D / 2) = u4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}; }
+
+    // row R of the group: sv = this lane's slice of its window sums; wr = where the slice goes in the record of the row's
+    // owner; wm = where the minima of the slice's groups go there (u16 each)
+    template <int R>
+    __device__ __forceinline__ void row(const uint32_t (&sv)[NRL], uint32_t* wr, unsigned short* wm)
+    {
+#pragma unroll
+        for (int i = 0; i < NRL; i += 4) *(u4*)(wr + i) = u4{sv[i], sv[i + 1], sv[i + 2], sv[i + 3]};
+#pragma unroll
+        for (int gq = 0; gq < NGH; ++gq) {
+            const uint32_t m = sel_pk_min(sel_pk_min(sv[4 * gq], sv[4 * gq + 1]), sel_pk_min(sv[4 * gq + 2], sv[4 * gq + 3]));
+            wm[gq] = (unsigned short)min(m & 0xffffu, m >> 16);
+        }
+    }
+
+    // after the LPP rows: the result for the row this lane owns (rec_own = its record)
+    __device__ __forceinline__ int finish(int tsum, const BMGeom& g, const uint32_t* rec_own, int* minsad, bool* rejected)
+    {
+        const u4 mn = *(const u4*)(rec_own + D / 2);                 // minima of the groups 2q (low half) and 2q + 1 (high half)
+        uint32_t kk[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+        for (int q = 0; q < NGD; ++q) {
+            const uint32_t gc = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
+            const uint32_t klo = __builtin_amdgcn_perm(mn[q], gc, 0x0C050400u);
+            const uint32_t khi = __builtin_amdgcn_perm(mn[q], gc, 0x0C070601u);
+            kk[q & 1] = min(min(kk[q & 1], klo), khi);
+        }
+        const uint32_t kmin = min(kk[0], kk[1]);
+        const int m1 = (int)(kmin >> 8);
+        const int gs = (int)(kmin & 0xffu);
+        const u4 grp = *(const u4*)(rec_own + 4 * gs);               // the four registers of the winning group
+        // (A) as a sum identity too: sum over ALL groups of max(T+1 - group minimum, 0) must equal what the winner's group and
+        // the neighbour's group contribute -- any other group with a minimum <= T adds a positive term.  Groups 2q / 2q+1
+        // sit in the low / high halves, so the (adjacent) winner and neighbour groups fall into different halves: a half that
+        // saturates (65535) holds more than its one expected term (<= 32767) -- the total stays above the expected total.
+        uint32_t T1 = 0, zg = 0;
+        if (g.uniq > 0) {
+            uint32_t T = (uint32_t)m1 + ((uint32_t)m1 * (uint32_t)g.uniq) / 100u;
+            T = min(T, 32766u);
+            T1 = T + 1u;
+            const uint32_t T1pk = T1 * 0x00010001u;
+            uint32_t z2[2] = {0, 0};
+#pragma unroll
+            for (int q = 0; q < NGD; ++q) z2[q & 1] = sel_pk_add_sat(z2[q & 1], sel_pk_sub_sat(T1pk, mn[q]));   // unused halves (0xffff) add 0
+            const uint32_t zq = NGD > 1 ? sel_pk_add_sat(z2[0], z2[1]) : z2[0];
+            zg = (zq & 0xffffu) + (zq >> 16);
+        }
+        uint32_t k3[2] = {0xffffffffu, 0xffffffffu};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t ec = (uint32_t)(2 * q) | ((uint32_t)(2 * q + 1) << 8);
+            const uint32_t klo = __builtin_amdgcn_perm(grp[q], ec, 0x0C050400u);
+            const uint32_t khi = __builtin_amdgcn_perm(grp[q], ec, 0x0C070601u);
+            k3[q & 1] = min(min(k3[q & 1], klo), khi);
+        }
+        const int e = (int)(min(k3[0], k3[1]) & 0xffu);
+        const int a = 8 * gs + e;
+        const bool has_n = a > 0, has_p = a + 1 < D;
+        const unsigned short* sv = (const unsigned short*)rec_own;
+        const int n_real = sv[has_n ? a - 1 : a];
+        const int p_real = sv[has_p ? a + 1 : a];
+        bool fail = tsum < g.tex;
+        if (g.uniq > 0) {
+            // the group a-1 or a+1 falls into, if that is not the winner's
+            const int nbq = (e == 0 && has_n) ? gs - 1 : (e == 7 && has_p) ? gs + 1 : gs;
+            const bool has_nb = nbq != gs;
+            const u4 nbg = *(const u4*)(rec_own + 4 * nbq);
+            const uint32_t nbmin = sv[D + nbq];                      // its minimum, from the minima behind the SADs
+            const uint32_t T1pk = T1 * 0x00010001u, nbmask = has_nb ? 0xffffffffu : 0u;
+            uint32_t zz[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                zz[q] = sel_pk_add_sat(sel_pk_sub_sat(T1pk, grp[q]), sel_pk_sub_sat(T1pk, nbg[q]) & nbmask);
+            const uint32_t zp = sel_pk_add_sat(sel_pk_add_sat(zz[0], zz[1]), sel_pk_add_sat(zz[2], zz[3]));
+            // a 16-bit half saturates at 65535, more than the (at most two) terms of {a-1, a, a+1} it can hold add up to:
+            // the total stays >= the expected total, with equality only if nothing saturated and nothing else contributed
+            const uint32_t z = (zp & 0xffffu) + (zp >> 16);
+            const auto term = [&](int v) -> uint32_t { return T1 > (uint32_t)v ? T1 - (uint32_t)v : 0u; };
+            const uint32_t tm1 = term(m1);
+            const uint32_t want = tm1 + (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);     // (B): inside the one or two groups
+            const uint32_t wantg = tm1 + (has_nb ? term((int)nbmin) : 0u);                             // (A): over the group minima
+            fail |= (z + zg) != (want + wantg);                      // z >= want and zg >= wantg: equal sums <=> both equal
+        }
+        int out = g.filtered;
+        if (!fail) {
+            const int pp = has_p ? p_real : n_real;
+            const int nn = has_n ? n_real : p_real;
+            const int den = pp + nn - 2 * m1 + abs(pp - nn);
+            const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
+            out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
+        }
+        *minsad = m1;
+        *rejected = fail;
+        return out;
+    }
+};
+
 }  // namespace rtdm
