@@ -51,6 +51,9 @@
 #ifndef RING_MINREC       // 0: GroupSelect (lane reductions) also where GroupSelectRec (minima in the owner's record) applies: A/B
 #define RING_MINREC 1
 #endif
+#ifndef RING_MINREC96     // 1: GroupSelectRec at D = 96 too (records of 240 instead of 208 bytes)
+#define RING_MINREC96 1
+#endif
 #ifndef RING_SPLIT_SELECT // 1: GroupSelect also for the two-lane configurations that default to the transposing selection
 #define RING_SPLIT_SELECT 0 // (D = 16, D = 32 except w = 9: measured 0-8 % slower there, profiles/r02_ring_split_select_ab.txt;
 #endif                      //  tools/ring_split_ab.sh)
@@ -83,8 +86,22 @@ struct RingGeom {
 
 // LPP = lanes per pixel: the D disparities of a pixel are split over LPP lanes of a wave (p + h * 64/LPP, h = 0..LPP-1), and
 // rows are processed in groups of LPP, one owner lane per row for the selection.
+// RPG = rows per group: the lanes with h < RPG own the group's rows; RPG < LPP (GroupSelectRec only: its lanes exchange
+// nothing) halves / quarters the number of selection records a wave needs -- what lets D = 192 and D = 256 (records of 432 /
+// 592 bytes) keep two workgroups per CU -- at the price of a selection that runs with RPG / LPP of its lanes.
+__host__ __device__ constexpr int ring_rpg(int D, int LPP) { return D >= 192 ? 4 : LPP; }
+
 template <int D, int WS, int LPP = 2>
 struct RingCfg {
+    static constexpr int RPG = ring_rpg(D, LPP);
+    // selection without transposing the lanes' slices (GroupSelect / GroupSelectRec): always for four and more lanes per pixel;
+    // with two lanes where it measured faster than transposing (tools/ring_split_ab.sh, profiles/r02_ring_split_select_ab.txt)
+    static constexpr bool SPLIT = LPP != 2 || D >= 48 || (D == 32 && WS == 9) || (RING_SPLIT_SELECT && RING_LDS_SELECT);
+    // the group minima live in the owner's record too and nothing crosses between the lanes (GroupSelectRec).  Not at D = 128
+    // with eight rows per group: 64 records of 304 bytes would leave one workgroup per CU.
+    static constexpr bool MINREC = SPLIT && RING_MINREC && !(D == 128 && RPG == 8) && !(D == 96 && !RING_MINREC96);
+    static_assert(RPG == LPP || MINREC, "GroupSelect's lane reductions need one owner per lane of a pixel");
+    using Rec = SelRecord<D, MINREC || !SPLIT>;
     static constexpr int NP = (WS + 3) / 4;        // 4-byte pieces of a window row
     static constexpr int W1 = WS + 1;              // ring slots
     static constexpr int PPW = 64 / LPP;           // pixels (columns) per wave
@@ -98,11 +115,11 @@ struct RingCfg {
     static constexpr int SLOT = ITEMS * 64;        // padded: every lane stores every item, no exec masking
     static constexpr int NSLOT = 3;                // staged rows in flight per wave
     static constexpr int STG = (NSLOT * SLOT + W1 * PPW + 3) & ~3;  // dwords per wave: staged rows + the texture prefix ring
-    static constexpr int WAVE_LDS = STG + 64 * SelRecord<D>::DWORDS;   // + the selection's per-lane records (rtdm_select.h)
+    static constexpr int WAVE_LDS = STG + PPW * RPG * Rec::DWORDS;   // + the selection's records, one per owner lane (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
     // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
-    static constexpr int WAVES = LPP == 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : (RING_REGS <= 72 && NRL <= 8) ? 4 : RING_REGS <= 112 ? 3 : 2;
+    static constexpr int WAVES = LPP >= 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : (RING_REGS <= 72 && NRL <= 8) ? 4 : RING_REGS <= 112 ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
     // border-column workgroups may ride in this kernel's grid (small launches); not in the four-wave forms, whose 128
     // registers the border body's code would overflow
@@ -111,8 +128,8 @@ struct RingCfg {
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
     static constexpr bool ROW_PTRS = !(LPP == 2 && RING_REGS > 88 && RING_REGS <= 112);
     // rows per trip of the unrolled row loop: whole rounds of the ring AND whole groups
-    static constexpr int TRIP = (W1 % LPP == 0) ? W1 : (2 * W1 % LPP == 0) ? 2 * W1 : 4 * W1;
-    static_assert(W1 % 2 == 0 && TRIP % LPP == 0 && TRIP % W1 == 0, "block sizes are odd");
+    static constexpr int TRIP = (W1 % RPG == 0) ? W1 : (2 * W1 % RPG == 0) ? 2 * W1 : 4 * W1;
+    static_assert(W1 % 2 == 0 && TRIP % RPG == 0 && TRIP % W1 == 0, "block sizes are odd");
 };
 
 template <int D, int WS, int LPP = 2>
@@ -209,10 +226,9 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
                                                                                    BorderGeom bg)
 {
     using C = RingCfg<D, WS, LPP>;
-    constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS, PPW = C::PPW;
-    // selection without transposing the lanes' slices (GroupSelect): always for four and eight lanes per pixel; with two
-    // lanes where it measured faster than transposing (tools/ring_split_ab.sh, profiles/r02_ring_split_select_ab.txt)
-    constexpr bool SPLIT = LPP != 2 || D >= 48 || (D == 32 && WS == 9) || (RING_SPLIT_SELECT && RING_LDS_SELECT);
+    constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS, PPW = C::PPW, RPG = C::RPG;
+    constexpr bool SPLIT = C::SPLIT, MINREC = C::MINREC;
+    constexpr int RECD = C::Rec::DWORDS;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
 
     // Workgroup ids go round-robin over the 8 XCDs, each with its own L2.  Item = (frame, strip, tile), tile fastest:
@@ -250,12 +266,11 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
 
     uint32_t* stg = lds + phi * C::WAVE_LDS;       // this wave's slice: nothing below is shared between waves
     uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][PPW] (the lanes of a pixel write the same value)
-    uint32_t* scr = stg + C::STG + lane * SelRecord<D>::DWORDS;       // this lane's selection record
-    uint32_t* scr_w = stg + C::STG + p * SelRecord<D>::DWORDS + h * NRL;   // SPLIT: where this lane's slice of the group's first row goes
-    // D <= 64: the group minima live in the owner's record too and nothing crosses between the lanes (GroupSelectRec)
-    constexpr bool MINREC = SPLIT && D <= 64 && RING_MINREC;
+    const bool owner = RPG == LPP || h < RPG;       // this lane owns row h of every group
+    uint32_t* scr = stg + C::STG + (owner ? lane : 0) * RECD;        // this lane's selection record (lanes that own nothing: never used)
+    uint32_t* scr_w = stg + C::STG + p * RECD + h * NRL;             // SPLIT: where this lane's slice of the group's first row goes
     using GSel = std::conditional_t<MINREC, GroupSelectRec<D, LPP>, GroupSelect<D, LPP>>;
-    unsigned short* scr_m = (unsigned short*)(stg + C::STG + p * SelRecord<D>::DWORDS + D / 2) + h * (NRL / 4);   // ... and the minima of its groups
+    unsigned short* scr_m = (unsigned short*)(stg + C::STG + p * RECD + D / 2) + h * (NRL / 4);   // ... and the minima of its groups
     if constexpr (MINREC) GroupSelectRec<D, LPP>::init(scr);
 
     // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
@@ -314,7 +329,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     uint32_t pt = 0;                                // texture prefix sum of the rows so far
 
     const int nsteps = (ys1 - ys0) + WS - 1;
-    const int nstepsg = (nsteps + LPP - 1) / LPP * LPP;   // rows go in groups of LPP; padded last rows are computed and dropped
+    const int nstepsg = (nsteps + RPG - 1) / RPG * RPG;   // rows go in groups of RPG; padded last rows are computed and dropped
     issue(Set0{}); issue(Set1{});
     commit(Set0{}, 0); commit(Set1{}, 1);           // rows 0 and 1 -> slots 0 and 1
     issue(Set0{});                                  // row 2: committed at the end of step 0
@@ -324,13 +339,13 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     char* const db = (char*)(disp.base + (size_t)f * disp.frame_e);
     char* const cb = (char*)(cost + (size_t)f * g.H * g.Ws);
     const int col = g.lofs + x;
-    constexpr int TF = (WS - 1) / LPP * LPP;        // first group with an output row; its row h is strip row TF + h - (WS - 1)
+    constexpr int TF = (WS - 1) / RPG * RPG;        // first group with an output row; its row h is strip row TF + h - (WS - 1)
     uint32_t dofs = (uint32_t)(((long long)(ys0 + TF + h - (WS - 1)) * (long long)disp.pitch_e + col) * 2);   // (mod 2^32; a row
     uint32_t cofs = (uint32_t)(((long long)(ys0 + TF + h - (WS - 1)) * (long long)g.Ws + col) * 2);           //  above the strip is never stored)
-    const uint32_t dstep = (uint32_t)(disp.pitch_e * 2 * LPP), cstep = (uint32_t)(g.Ws * 2 * LPP);
+    const uint32_t dstep = (uint32_t)(disp.pitch_e * 2 * RPG), cstep = (uint32_t)(g.Ws * 2 * RPG);
     const bool masked_col = g.mask_cols && (col < g.vx0 || col >= g.vx1);
 
-    uint32_t S[LPP][NRL];
+    uint32_t S[RPG][NRL];
 #ifdef RING_STAMPS
     unsigned long long stamp_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory");
@@ -379,14 +394,14 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     // One trip of the outer loop = whole rounds of the ring AND whole row groups (TRIP rows), unrolled: every row step has
     // its ring slot -- its registers -- fixed at compile time.
     for (int t0 = 0; t0 < nstepsg; t0 += C::TRIP) {
-        ring_for_groups(std::make_integer_sequence<int, C::TRIP / LPP>{}, [&](auto Uc) -> bool {
-            constexpr int U = LPP * decltype(Uc)::value;
+        ring_for_groups(std::make_integer_sequence<int, C::TRIP / RPG>{}, [&](auto Uc) -> bool {
+            constexpr int U = RPG * decltype(Uc)::value;
             const int t = t0 + U;
             if (t >= nstepsg) return false;
             RING_STAMP(0);                                          // (loop overhead + whatever precedes the group)
             GSel gsel;
             int tsum = 0;
-            ring_for_rows(std::make_integer_sequence<int, LPP>{}, [&](auto Rc) {
+            ring_for_rows(std::make_integer_sequence<int, RPG>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 RowRegs<D, WS, LPP> rw;
                 lds_row(rw);
@@ -398,14 +413,14 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
                 if constexpr (SPLIT && RING_ABL == 0) {
                     // the row's slice goes to its owner's record and into the group minima at once: S[R] is dead after this
                     // (also while the window fills: a branch around it turns into selects on all of gsel's state)
-                    if constexpr (MINREC) gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), scr_m + R * (PPW * SelRecord<D>::DWORDS * 2));
-                    else gsel.template row<R>(S[R], scr_w + R * (PPW * SelRecord<D>::DWORDS), (uint32_t)(h * (NRL / 4)));
+                    if constexpr (MINREC) gsel.template row<R>(S[R], scr_w + R * (PPW * RECD), scr_m + R * (PPW * RECD * 2));
+                    else gsel.template row<R>(S[R], scr_w + R * (PPW * RECD), (uint32_t)(h * (NRL / 4)));
                 }
             });
-            if (t + LPP - 1 < WS - 1) return true;                  // the window is still filling
-            // the lanes p + h PPW hold the LPP slices of a pixel for the rows t .. t+LPP-1; the lane with h = k owns row t+k
+            if (t + RPG - 1 < WS - 1) return true;                  // the window is still filling
+            // the lanes p + h PPW hold the LPP slices of a pixel for the rows t .. t+RPG-1; the lane with h = k < RPG owns row t+k
             const int y = ys0 + (t - (WS - 1)) + h;
-            const bool row_ok = y >= ys0 && y < ys1;
+            const bool row_ok = owner && y >= ys0 && y < ys1;
             const uint32_t dof = dofs, cof = cofs;
             dofs += dstep; cofs += cstep;
             // Selection is skipped for a wave none of whose pixels can produce a disparity here (untextured, outside the
@@ -426,9 +441,9 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
 #pragma unroll
                     for (int i = 0; i < NRL; ++i) {
 #if RING_ABL == 5 || RING_ABL == 6
-                        rr[i] = S[0][i]; rr[NRL + i] = S[LPP - 1][i];
+                        rr[i] = S[0][i]; rr[NRL + i] = S[RPG - 1][i];
 #else
-                        const auto sw = __builtin_amdgcn_permlane32_swap(S[0][i], S[LPP - 1][i], false, false);
+                        const auto sw = __builtin_amdgcn_permlane32_swap(S[0][i], S[RPG - 1][i], false, false);
                         rr[i] = sw[0]; rr[NRL + i] = sw[1];
 #endif
                     }
@@ -483,13 +498,14 @@ static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g
 // registers per lane leaves room for two waves per SIMD.  Four lanes per pixel: the D = 64 ones, whose two-lane ring holds
 // them at two waves, and D = 96 (D = 32 with four lanes measured 0-8 % slower than with two: not instantiated).  Eight
 // lanes: D = 128.
-#ifdef RTDM_RING_DEV      // development builds (tools/ring_isa.sh): the headline instantiation only
-#define RTDM_RING_TABLE(X) X(64, 9, 4)
+#ifdef RTDM_RING_DEV      // development builds (tools/ring_isa.sh): -DRTDM_RING_DEV="X(64, 9, 4)" = these instantiations only
+#define RTDM_RING_TABLE(X) RTDM_RING_DEV
 #else
 #define RTDM_RING_TABLE(X) X(64, 9, 2) X(64, 7, 2) X(64, 5, 2) X(32, 7, 2) X(32, 9, 2) X(32, 11, 2) X(32, 13, 2) X(48, 7, 2) X(48, 9, 2) \
                            X(16, 5, 2) X(16, 7, 2) X(16, 9, 2) X(64, 9, 4) X(64, 7, 4) X(64, 5, 4) X(64, 11, 4) X(64, 13, 4) \
                            X(128, 7, 8) X(128, 9, 8) X(128, 11, 8) X(128, 13, 8) X(96, 7, 4) X(96, 9, 4) X(96, 11, 4) X(96, 13, 4) X(48, 11, 2) X(48, 13, 2) \
-                           X(16, 11, 2) X(16, 13, 2) X(32, 5, 2) X(32, 15, 2) X(48, 5, 2) X(64, 15, 4) X(128, 15, 8)
+                           X(16, 11, 2) X(16, 13, 2) X(32, 5, 2) X(32, 15, 2) X(48, 5, 2) X(64, 15, 4) X(128, 15, 8) \
+                           X(192, 9, 8) X(192, 11, 8) X(192, 13, 8) X(192, 15, 8) X(256, 9, 16) X(256, 11, 16) X(256, 13, 16) X(256, 15, 16)
 #endif
 
 // rtdm_debug_search_kernel (a process-wide A/B switch; one atomic word so that a launch on another thread sees a consistent
@@ -514,7 +530,7 @@ static int ring_lpp(const BMGeom& g)
     const int forced = ring_forced_lpp(), want = forced ? forced : env;
     if (want && (have & want) == want) return want;
     // measured (tools/ab_ring.py): more lanes per pixel win where the ring holds the two-lane form at two waves per SIMD
-    return (have & 8) ? 8 : (have & 4) ? 4 : (have & 2) ? 2 : 0;
+    return (have & 16) ? 16 : (have & 8) ? 8 : (have & 4) ? 4 : (have & 2) ? 2 : 0;
 }
 
 int ring_lanes_per_pixel(const BMGeom& g) { return ring_lpp(g); }

@@ -463,7 +463,7 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
     {
         const bool ring = fast && ring_search_supported(g);
         const int lpp = ring ? ring_lanes_per_pixel(g) : 0;
-        bm->variant = ring ? (lpp == 8 ? "fast_ring8_qsad" : lpp == 4 ? "fast_ring4_qsad" : "fast_ring_qsad") : fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
+        bm->variant = ring ? (lpp == 16 ? "fast_ring16_qsad" : lpp == 8 ? "fast_ring8_qsad" : lpp == 4 ? "fast_ring4_qsad" : "fast_ring_qsad") : fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
         Plane8W Lp{ln.dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{ln.dRp, bm->ppitch, bm->ppitch * (size_t)H};
         stage_begin(bm, RTDM_STAGE_PREFILTER, n, s, &ev);
         launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s);

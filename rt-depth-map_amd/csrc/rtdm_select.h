@@ -155,8 +155,14 @@ __device__ __forceinline__ int select_disparity(const uint32_t (&rr)[D / 2], int
 // 16-byte read and sad[a-1], sad[a+1] with two 2-byte reads -- in place of the 42 + 14 v_cndmask of the register tree --
 // and both round trips are in flight while the uniqueness sum (which needs only minsad) is computed.
 // scr: this LANE's record, SelRecord<D>::DWORDS dwords apart from its neighbours', 16-byte aligned; private to the wave.
-template <int D> struct SelRecord { static constexpr int DWORDS = D / 2 + 4; };   // 12, 20, 28, 36: eight consecutive lanes' 16-byte
-                                                                                  // stores start in eight different bank quads
+// D/2 SAD dwords + D/16 dwords of packed group minima (GroupSelectRec), rounded up to an ODD number of 16-byte quads so that
+// eight consecutive lanes' 16-byte stores start in eight different bank quads: 12, 20, 28, 36 dwords for D = 16 .. 64 (the
+// minima fill what used to be padding), 60 / 76 / 108 / 148 for D = 96 / 128 / 192 / 256
+// (MINIMA = false, GroupSelect at D = 96 / 128: D/2 + 4 = 52 / 68 dwords)
+template <int D, bool MINIMA = true> struct SelRecord {
+    static constexpr int QUADS = MINIMA ? (D / 2 + D / 16 + 3) / 4 : D / 8 + 1;
+    static constexpr int DWORDS = 4 * (QUADS | 1);
+};
 template <int D>
 __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2], int tsum, const BMGeom& g, uint32_t* scr,
                                                     int* minsad, bool* rejected)
@@ -427,14 +433,17 @@ struct GroupSelect {
 // and 12 registers of per-group state (mm, kpart) less.  Same results: the tests (A) and (B) of GroupSelect, same values.
 template <int D, int LPP>
 struct GroupSelectRec {
-    static constexpr int NRL = D / (2 * LPP), NGH = NRL / 4, NG = D / 8, NGD = (NG + 1) / 2;
-    static_assert(D == 16 || D == 32 || D == 48 || D == 64, "the minima must fit the record's four padding dwords");
+    static constexpr int NRL = D / (2 * LPP), NGH = NRL / 4, NG = D / 8, NGD = NG / 2, NGQ = (NGD + 3) / 4;
+    static_assert(D % 16 == 0 && D / 2 + 4 * NGQ <= SelRecord<D>::DWORDS, "the minima live behind the SADs of the record");
     static_assert(NRL % 4 == 0, "a lane's slice must be whole groups of eight disparities");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
     // once per kernel: unused minima slots of this lane's record never win and never count
     static __device__ __forceinline__ void init(uint32_t* rec_own)
-    { *(u4*)(rec_own + D / 2) = u4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}; }
+    {
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) *(u4*)(rec_own + D / 2 + 4 * i) = u4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+    }
 
     // row R of the group: sv = this lane's slice of its window sums; wr = where the slice goes in the record of the row's
     // owner; wm = where the minima of the slice's groups go there (u16 each)
@@ -453,7 +462,12 @@ struct GroupSelectRec {
     // after the LPP rows: the result for the row this lane owns (rec_own = its record)
     __device__ __forceinline__ int finish(int tsum, const BMGeom& g, const uint32_t* rec_own, int* minsad, bool* rejected)
     {
-        const u4 mn = *(const u4*)(rec_own + D / 2);                 // minima of the groups 2q (low half) and 2q + 1 (high half)
+        uint32_t mn[4 * NGQ];                                        // minima of the groups 2q (low half) and 2q + 1 (high half)
+#pragma unroll
+        for (int i = 0; i < NGQ; ++i) {
+            const u4 v = *(const u4*)(rec_own + D / 2 + 4 * i);
+            mn[4 * i] = v[0]; mn[4 * i + 1] = v[1]; mn[4 * i + 2] = v[2]; mn[4 * i + 3] = v[3];
+        }
         uint32_t kk[2] = {0xffffffffu, 0xffffffffu};
 #pragma unroll
         for (int q = 0; q < NGD; ++q) {

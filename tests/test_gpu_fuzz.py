@@ -112,7 +112,9 @@ def test_every_fast_instantiation(pkg, oracle, synth, D, pieces):
 RING_TABLE = [(64, 9, 2), (64, 7, 2), (64, 5, 2), (32, 7, 2), (32, 9, 2), (32, 11, 2), (32, 13, 2), (48, 7, 2), (48, 9, 2),
               (16, 5, 2), (16, 7, 2), (16, 9, 2), (64, 9, 4), (64, 7, 4), (64, 5, 4), (64, 11, 4), (64, 13, 4),
               (128, 7, 8), (128, 9, 8), (128, 11, 8), (128, 13, 8), (96, 7, 4), (96, 9, 4), (96, 11, 4), (96, 13, 4),
-              (48, 11, 2), (48, 13, 2), (16, 11, 2), (16, 13, 2), (32, 5, 2), (32, 15, 2), (48, 5, 2), (64, 15, 4), (128, 15, 8)]
+              (48, 11, 2), (48, 13, 2), (16, 11, 2), (16, 13, 2), (32, 5, 2), (32, 15, 2), (48, 5, 2), (64, 15, 4), (128, 15, 8),
+              # round 3: rows per group < lanes per pixel (D = 192: eight lanes, four rows; D = 256: sixteen lanes, four rows)
+              (192, 9, 8), (192, 11, 8), (192, 13, 8), (192, 15, 8), (256, 9, 16), (256, 11, 16), (256, 13, 16), (256, 15, 16)]
 
 
 @pytest.mark.parametrize("D,w,lpp", RING_TABLE)
@@ -134,7 +136,7 @@ def test_every_ring_instantiation(pkg, oracle, synth, D, w, lpp):
             m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, **kw)
             if roi1: m.setROI1(roi1)
             got = m.compute(L, R)
-            assert m.search_variant == {2: "fast_ring_qsad", 4: "fast_ring4_qsad", 8: "fast_ring8_qsad"}[lpp], (D, w, m.search_variant)
+            assert m.search_variant == {2: "fast_ring_qsad", 4: "fast_ring4_qsad", 8: "fast_ring8_qsad", 16: "fast_ring16_qsad"}[lpp], (D, w, m.search_variant)
             m.close()
             okw = dict(kw); okw.update(numDisparities=D, blockSize=w)
             if roi1: okw["roi1"] = roi1

@@ -262,3 +262,45 @@ def test_two_gpus_over_rccl_when_the_box_has_them():
     assert out["parity_ok"] is True and out["equals_direct_call"] is True
     ph = out["phase_ms_per_pass"]
     assert ph["chunks"] == 4 and ph["scatter_ms"] > 0 and ph["compute_ms"] > 0 and ph["gather_ms"] > 0
+
+
+# ---- the reference's own parameter set (main.cpp:134-135 + cmdline-parser.cpp:22: d = 192, 13 x 13 at EVERY resolution) ---
+# on the ring kernel now (eight lanes per pixel, four rows per group), as a device batch: autotuned strips, side-stream border
+def test_reference_default_1280x720_d192_w13_batch32(pkg, oracle, synth):
+    import torch
+    n, W, H, D, w = 32, 1280, 720, 192, 13
+    dL = torch.empty((n, H, W), dtype=torch.uint8, device="cuda"); dR = torch.empty_like(dL)
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    pkg.synth_pairs_device(dL, dR, first_frame=300, numDisparities=D, stream=st)
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, width=W, height=H, max_batch=n)
+    outs = []
+    for _ in range(3):                      # model, measured strip count, its use
+        dD.zero_()
+        m.compute_device(dL, dR, dD, st)
+        torch.cuda.synchronize()
+        outs.append(dD.clone())
+    assert m.search_variant == "fast_ring8_qsad"
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    for i in (0, 17, 31):
+        assert_same(outs[2][i].cpu().numpy(), oracle.bm_compute(dL[i].cpu().numpy(), dR[i].cpu().numpy(), numDisparities=D, blockSize=w, nthreads=16))
+    m.close()
+
+
+@pytest.mark.parametrize("W,H,crop", [(320, 240, (49, 46, 233, 156)), (640, 480, (63, 61, 534, 378)), (1280, 720, (192, 177, 934, 404))])
+def test_reference_call_shape_d192_w13_views_with_roi1(pkg, oracle, synth, W, H, crop):
+    # estimator.cpp:33-36,54-56: roif-sized views at the crop origin of full-pitch planes, setROI1 before compute;
+    # d = 192 does not fit the 233-wide crop (everything FILTERED there, as in the reference)
+    cx, cy, cw, ch = crop
+    L, R = synth.make_pair(synth.STREAM_SEED + 21 + W, W, H, 64)
+    Lv, Rv = L[cy:cy + ch, cx:cx + cw], R[cy:cy + ch, cx:cx + cw]
+    plane = np.full((H, W), 777, np.int16)
+    Ov = plane[cy:cy + ch, cx:cx + cw]
+    roi = (cw // 3, ch // 5, cw // 3, ch // 2)
+    m = pkg.HIPMatcher(numOfDisparities=192, blockSize=13, width=cw, height=ch)
+    m.setROI1(roi)
+    m.compute(Lv, Rv, Ov)
+    m.close()
+    assert_same(Ov, oracle.bm_compute(np.ascontiguousarray(Lv), np.ascontiguousarray(Rv), numDisparities=192, blockSize=13, roi1=roi))
+    guard = plane.copy(); guard[cy:cy + ch, cx:cx + cw] = 777
+    assert (guard == 777).all()
