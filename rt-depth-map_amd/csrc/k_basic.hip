@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void k_prefilter8(Plane8 L, Plane8 R, Plane8W 
     const uint8_t* src = S.base + (size_t)f * S.frame;
     uint8_t* dst = O.base + (size_t)f * O.frame + (size_t)y * O.pitch + x0;
     const int npair = (H >= 2) ? (H & ~1) : 0;
-    unsigned long long out = (unsigned long long)cap * 0x0101010101010101ull;
+    const int off = cap + PREFILTER_BIAS;
+    unsigned long long out = (unsigned long long)off * 0x0101010101010101ull;
     if (y < npair) {
         const int ya = (y > 0) ? y - 1 : 1;
         const int yb = (y < H - 1) ? y + 1 : H - 2;
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void k_prefilter8(Plane8 L, Plane8 R, Plane8W 
             const int x = x0 + k;
             int g = s[k + 2] - s[k];
             g = g < -cap ? -cap : (g > cap ? cap : g);
-            const int v = (x == 0 || x >= W - 1) ? cap : g + cap;
+            const int v = (x == 0 || x >= W - 1) ? off : g + off;
             out |= (unsigned long long)v << (8 * k);
         }
     }
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void k_prefilter16(Plane8 L, Plane8 R, Plane8W
     uint8_t* dst = O.base + (size_t)f * O.frame + (size_t)ys * O.pitch + x0;
     const int npair = (H >= 2) ? (H & ~1) : 0;
     const bool has_prev = x0 > 0, has_next = x0 + 16 < W;
-    const uint32_t capb = cap * 0x01010101u;
+    const uint32_t capb = (uint32_t)(cap + PREFILTER_BIAS) * 0x01010101u;   // what edge columns and an odd last row hold
     const uint4 capv = make_uint4(capb, capb, capb, capb);
     // Packed 16-bit arithmetic, two columns per instruction (the scalar form ran 27 VALU instructions per pixel and was
     // VALU bound at 87 % busy -- not HBM bound, as a prefilter should be): the 18 bytes b[0..17] = left neighbour, the 16
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void k_prefilter16(Plane8 L, Plane8 R, Plane8W
     const auto pk = [](uint32_t v) { return __builtin_bit_cast(s2, v); };
     const auto un = [](s2 v) { return __builtin_bit_cast(uint32_t, v); };
     const s2 capp = pk((uint32_t)cap * 0x00010001u), ncapp = pk((uint32_t)(-cap & 0xffff) * 0x00010001u);
+    const s2 offp = pk((uint32_t)(cap + PREFILTER_BIAS) * 0x00010001u);
     // bytes of the output that are the frame's first / last column (or padding): they hold `cap`
     uint32_t em[4];
 #pragma unroll
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void k_prefilter16(Plane8 L, Plane8 R, Plane8W
                     for (int i = 0; i < 8; ++i) {
                         const s2 c = hd[(j - 1) % 3][i];
                         s2 g = hd[(j - 2) % 3][i] + hd[j % 3][i] + c + c;          // |g| <= 1020
-                        g = __builtin_elementwise_min(__builtin_elementwise_max(g, ncapp), capp) + capp;
+                        g = __builtin_elementwise_min(__builtin_elementwise_max(g, ncapp), capp) + offp;
                         v[i] = un(g);
                     }
                     uint32_t w[4];
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void k_prefilter1(Plane8 L, Plane8 R, Plane8W 
     const Plane8W O = right ? Rp : Lp;
     const uint8_t* src = S.base + (size_t)f * S.frame;
     const int npair = (H >= 2) ? (H & ~1) : 0;
-    int v = cap;
+    int v = cap + PREFILTER_BIAS;
     if (y < npair && x > 0 && x < W - 1) {
         const int ya = (y > 0) ? y - 1 : 1;
         const int yb = (y < H - 1) ? y + 1 : H - 2;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void k_prefilter1(Plane8 L, Plane8 R, Plane8W 
         const uint8_t* rb = src + (size_t)yb * S.pitch;
         int g = ((int)ra[x + 1] - (int)ra[x - 1]) + 2 * ((int)rc[x + 1] - (int)rc[x - 1]) + ((int)rb[x + 1] - (int)rb[x - 1]);
         g = g < -cap ? -cap : (g > cap ? cap : g);
-        v = g + cap;
+        v = g + cap + PREFILTER_BIAS;
     }
     O.base[(size_t)f * O.frame + (size_t)y * O.pitch + x] = (uint8_t)v;
 }

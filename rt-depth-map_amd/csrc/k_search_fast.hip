@@ -133,11 +133,11 @@ __global__ __launch_bounds__(256, (FAST_TIGHT_BOUNDS ? (D >= 192 ? 3 : D >= 128 
     const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
     const int Lbase = g.lofs + x_tile - r;   // image column of tile-row byte 0 (left)
     const int Rbase = g.rofs + x_tile - r;   //                                  (right)
-    const uint32_t capb = (uint32_t)(g.cap + 1) * 0x01010101u;
+    const uint32_t capb = (uint32_t)(g.cap + PREFILTER_BIAS) * 0x01010101u;
 
     // --- staging: every item = one dword of one byte-shifted copy ------------------------------
     // item idx in [0, 4*LWD): left copy c = idx / LWD, dword m = idx % LWD; then the right copies.
-    // copy c, dword m holds tile-row bytes [c + 4m, c + 4m + 4), biased by +1.
+    // copy c, dword m holds tile-row bytes [c + 4m, c + 4m + 4) (the planes are biased by +1: rtdm_kernels.h).
     int it_q[ITEMS], it_sh[ITEMS];
     bool it_r[ITEMS], it_ok[ITEMS];
 #pragma unroll
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, (FAST_TIGHT_BOUNDS ? (D >= 192 ? 3 : D >= 128 
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint32_t v = __builtin_amdgcn_alignbyte(pre[it][1], pre[it][0], (uint32_t)it_sh[it]);
-            if (it_ok[it]) lds[slot * SLOT + tid + it * 256] = v + 0x01010101u;
+            if (it_ok[it]) lds[slot * SLOT + tid + it * 256] = v;           // (the planes carry the +1 bias themselves)
         }
     };
 

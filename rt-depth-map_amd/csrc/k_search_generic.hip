@@ -88,8 +88,9 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
             for (int k = tid; k < TCH + D; k += 256) {
                 const int x = rb0 + k;
                 const bool wrap = g.legacy && x >= g.W && x - g.W < g.W;
-                Rn[k] = x < g.W ? rrow[x] : (wrap && rin1 < g.H) ? rnext[x - g.W] : 0;
-                Ro[k] = x < g.W ? rrow_o[x] : (wrap && rout1 < g.H) ? rnext_o[x - g.W] : 0;
+                // (past the last row the 3.x code reads what follows the plane: zeros in the oracle = the bias here)
+                Rn[k] = x < g.W ? rrow[x] : (wrap && rin1 < g.H) ? rnext[x - g.W] : PREFILTER_BIAS;
+                Ro[k] = x < g.W ? rrow_o[x] : (wrap && rout1 < g.H) ? rnext_o[x - g.W] : PREFILTER_BIAS;
             }
         }
         __syncthreads();
@@ -104,8 +105,8 @@ __global__ __launch_bounds__(256) void k_search_generic(Plane8 Lp, Plane8 Rp, Pl
             }
         }
         for (int jj = tid; jj < TCH; jj += 256) {
-            int a = abs((int)Ln[jj] - g.cap);
-            if (sub) a -= abs((int)Lo[jj] - g.cap);
+            int a = abs((int)Ln[jj] - (g.cap + PREFILTER_BIAS));          // (the planes are biased: rtdm_kernels.h)
+            if (sub) a -= abs((int)Lo[jj] - (g.cap + PREFILTER_BIAS));
             Tcol[jj] += a;
         }
         __syncthreads();

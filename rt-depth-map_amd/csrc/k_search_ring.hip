@@ -51,6 +51,12 @@
 #ifndef RING_MINREC       // 0: GroupSelect (lane reductions) also where GroupSelectRec (minima in the owner's record) applies: A/B
 #define RING_MINREC 1
 #endif
+#ifndef RING_STATIC_SLOTS // 1: four staging slots where a trip of the row loop is a multiple of four rows: the slot of every unrolled row step
+#define RING_STATIC_SLOTS 1 // is a compile-time constant and all LDS addresses are base + immediate (3-4 VALU per row less)
+#endif
+#ifndef RING_DIRECT_LOADS // 1: a staged dword is ONE (unaligned) global load at uniform row base + lane offset, stored as it is; 0: two
+#define RING_DIRECT_LOADS 1 // aligned dwords per lane and row, shifted into place by v_alignbyte
+#endif
 #ifndef RING_MINREC96     // 1: GroupSelectRec at D = 96 too (records of 240 instead of 208 bytes)
 #define RING_MINREC96 1
 #endif
@@ -80,6 +86,7 @@ struct RingGeom {
     int tiles, strips;   // column tiles x row strips per frame
     unsigned nitems;     // workgroups over the whole batch
     unsigned chunk;      // ceil(nitems / 8): consecutive items one XCD works through (0: no remapping)
+    uint32_t rdelta;     // the right prefiltered plane lies this many bytes behind the left one (direct loads)
     unsigned nborder;    // border-column workgroups in FRONT of the tile workgroups (single frames and small batches, where a
     int bgx, bgy;        // second launch or a side stream costs more than it hides; rtdm_border.h); 0: none
 };
@@ -89,7 +96,17 @@ struct RingGeom {
 // RPG = rows per group: the lanes with h < RPG own the group's rows; RPG < LPP (GroupSelectRec only: its lanes exchange
 // nothing) halves / quarters the number of selection records a wave needs -- what lets D = 192 and D = 256 (records of 432 /
 // 592 bytes) keep two workgroups per CU -- at the price of a selection that runs with RPG / LPP of its lanes.
-__host__ __device__ constexpr int ring_rpg(int D, int LPP) { return D >= 192 ? 4 : LPP; }
+#ifndef RING_RPG96        // A/B (tools/ring_dev.py with `make variant`): rows per group at D = 96, 128, 256
+#define RING_RPG96 4
+#endif
+#ifndef RING_RPG128       // (measured: four rows per group + GroupSelectRec 6-8 % faster than eight + GroupSelect; D = 96 with two
+#define RING_RPG128 4     //  rows and D = 256 with eight are slower than four: profiles/r03_ring_rows_per_group_ab.txt)
+#endif
+#ifndef RING_RPG256
+#define RING_RPG256 4
+#endif
+__host__ __device__ constexpr int ring_rpg(int D, int LPP)
+{ return D == 256 ? RING_RPG256 : D >= 192 ? 4 : D == 128 ? RING_RPG128 : D == 96 ? RING_RPG96 : LPP; }
 
 template <int D, int WS, int LPP = 2>
 struct RingCfg {
@@ -113,7 +130,13 @@ struct RingCfg {
     static constexpr int RWD = PPW + D / 4 + NP;   //                                 right row
     static constexpr int ITEMS = (LWD + RWD + 63) / 64;
     static constexpr int SLOT = ITEMS * 64;        // padded: every lane stores every item, no exec masking
-    static constexpr int NSLOT = 3;                // staged rows in flight per wave
+    // rows per trip of the unrolled row loop: whole rounds of the ring AND whole groups
+    static constexpr int TRIP = (W1 % RPG == 0) ? W1 : (2 * W1 % RPG == 0) ? 2 * W1 : 4 * W1;
+    static_assert(W1 % 2 == 0 && TRIP % RPG == 0 && TRIP % W1 == 0, "block sizes are odd");
+    // staged rows in flight per wave: three (row t is read while t+1 waits and t+2 arrives), or four where that makes the
+    // slot of every unrolled step a constant (one item per row only: ds_read2's 8-bit dword offsets must reach the slots)
+    static constexpr bool STATIC_SLOTS = RING_STATIC_SLOTS && ITEMS == 1 && TRIP % 4 == 0;
+    static constexpr int NSLOT = STATIC_SLOTS ? 4 : 3;
     static constexpr int STG = (NSLOT * SLOT + W1 * PPW + 3) & ~3;  // dwords per wave: staged rows + the texture prefix ring
     static constexpr int WAVE_LDS = STG + PPW * RPG * Rec::DWORDS;   // + the selection's records, one per owner lane (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
@@ -127,9 +150,6 @@ struct RingCfg {
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
     static constexpr bool ROW_PTRS = !(LPP == 2 && RING_REGS > 88 && RING_REGS <= 112);
-    // rows per trip of the unrolled row loop: whole rounds of the ring AND whole groups
-    static constexpr int TRIP = (W1 % RPG == 0) ? W1 : (2 * W1 % RPG == 0) ? 2 * W1 : 4 * W1;
-    static_assert(W1 % 2 == 0 && TRIP % RPG == 0 && TRIP % W1 == 0, "block sizes are odd");
 };
 
 template <int D, int WS, int LPP = 2>
@@ -262,7 +282,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
     const int Lbase = g.lofs + x_tile - r + phi;   // image column of byte 0 of this wave's copy (left)
     const int Rbase = g.rofs + x_tile - r + phi;   //                                            (right)
-    const uint32_t capb = (uint32_t)(g.cap + 1) * 0x01010101u;
+    const uint32_t capb = (uint32_t)(g.cap + PREFILTER_BIAS) * 0x01010101u;
 
     uint32_t* stg = lds + phi * C::WAVE_LDS;       // this wave's slice: nothing below is shared between waves
     uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][PPW] (the lanes of a pixel write the same value)
@@ -273,11 +293,50 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     unsigned short* scr_m = (unsigned short*)(stg + C::STG + p * RECD + D / 2) + h * (NRL / 4);   // ... and the minima of its groups
     if constexpr (MINREC) GroupSelectRec<D, LPP>::init(scr);
 
-    // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4), biased by +1 ----------
+    // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4) (biased planes) ---------
     // Unconditional loads: bytes past a row's end only ever reach lanes that are not `active`, and the prefiltered planes
     // are allocated with 1 KB of slack behind the last row (rtdm_api.hip).  Two rows of loads are in flight (pre[0/1]).
     const int row0 = ys0 - r;
     const int Hm1 = g.H - 1;
+#if RING_DIRECT_LOADS
+    // One load per staged dword: address = the left plane's row (wave-uniform: lives in SGPRs and advances on the scalar
+    // unit) + a 32-bit lane offset -- the right plane lies rg.rdelta bytes behind the left one (one allocation, rtdm_api.hip).
+    // The byte phase makes the address unaligned; the memory pipeline takes unaligned dwords, and what arrives is what gets
+    // staged: no second dword, no v_alignbyte, no 64-bit pointer arithmetic per lane.
+    const uint8_t* rowp = Lb + (size_t)row0 * Lp.pitch;
+    uint32_t loff[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int idx = lane + it * 64;
+        const bool isr = idx >= LWD;
+        const int m = isr ? idx - LWD : idx;
+        loff[it] = (uint32_t)((isr ? Rbase : Lbase) + 4 * m) + (isr ? rg.rdelta : 0u);
+    }
+    int next_row = row0;
+    uint32_t pre[2][ITEMS];
+    auto issue = [&](auto Sc) {                     // loads of the next row into register set Sc; rows past H-1 repeat H-1
+        constexpr int SET = decltype(Sc)::value;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+#if RING_ABL == 3
+            pre[SET][it] = (uint32_t)next_row * 0x01020304u + lane;
+#else
+            // (the empty asm keeps the zero-extension of the offset next to the load: hoisted out of the loop as a 64-bit
+            //  value it hides the "SGPR base + 32-bit VGPR offset" addressing mode and costs a 64-bit VALU add per load)
+            asm volatile("" : "+v"(loff[it]));
+            pre[SET][it] = *(const uint32_t*)(rowp + loff[it]);
+#endif
+        }
+        rowp += next_row < Hm1 ? Lp.pitch : 0;
+        ++next_row;
+    };
+    auto commit = [&](auto Sc, auto slot) {        // slot: an int, or an integral_constant where the slots are static
+        constexpr int SET = decltype(Sc)::value;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) stg[slot * SLOT + lane + it * 64] = pre[SET][it];   // (the planes carry the +1 bias themselves)
+        __builtin_amdgcn_wave_barrier();           // the wave's later reads stay behind these writes (LDS is in order per wave)
+    };
+#else
     const uint8_t* src[ITEMS];                      // where the next row to be issued starts, per item
     int it_sh[ITEMS];
 #pragma unroll
@@ -307,15 +366,16 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
         for (int it = 0; it < ITEMS; ++it) src[it] += adv;
         ++next_row;
     };
-    auto commit = [&](auto Sc, int slot) {
+    auto commit = [&](auto Sc, auto slot) {        // slot: an int, or an integral_constant where the slots are static
         constexpr int SET = decltype(Sc)::value;
 #pragma unroll
         for (int it = 0; it < ITEMS; ++it) {
             const uint32_t v = __builtin_amdgcn_alignbyte(pre[SET][it][1], pre[SET][it][0], (uint32_t)it_sh[it]);
-            stg[slot * SLOT + lane + it * 64] = v + 0x01010101u;
+            stg[slot * SLOT + lane + it * 64] = v;                          // (the planes carry the +1 bias themselves)
         }
         __builtin_amdgcn_wave_barrier();           // the wave's later reads stay behind these writes (LDS is in order per wave)
     };
+#endif
     using Set0 = std::integral_constant<int, 0>;
     using Set1 = std::integral_constant<int, 1>;
 
@@ -360,9 +420,15 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     // with a wave-uniform step; laundered so that every window offset folds into a ds_read immediate of ITS base)
     // (32-bit LDS addresses, not C++ pointers: a generic pointer that went through an asm loses its address space and
     //  turns every read into a flat load -- measured 2x slower)
+    // Static slots (four of them, trip a multiple of four rows): the slot is a constant of the unrolled step and the three
+    // registers never move -- every read is base + immediate.
     uint32_t la_cur = lds_addr(stg + p), ra_cur = lds_addr(stg + LWD + p + h * NGL), ro_cur = ra_cur + 4;
-    const auto lds_row = [&](RowRegs<D, WS, LPP>& rw) {
-        if constexpr (C::ROW_PTRS) {
+    if constexpr (C::STATIC_SLOTS) asm volatile("" : "+v"(la_cur), "+v"(ra_cur), "+v"(ro_cur));
+    const auto lds_row = [&](auto SLc, RowRegs<D, WS, LPP>& rw) {
+        if constexpr (C::STATIC_SLOTS) {
+            constexpr uint32_t off = (uint32_t)(decltype(SLc)::value * SLOT * 4);
+            ring_load_row<D, WS, LPP>(lds_at(la_cur + off), lds_at(ra_cur + off), lds_at(ro_cur + off), rw);
+        } else if constexpr (C::ROW_PTRS) {
             asm volatile("" : "+v"(la_cur), "+v"(ra_cur), "+v"(ro_cur));
             ring_load_row<D, WS, LPP>(lds_at(la_cur), lds_at(ra_cur), lds_at(ro_cur), rw);
             const uint32_t adv = (uint32_t)((sl_cur == 2 ? -2 * SLOT : SLOT) * 4);   // (before the step moves sl_cur on)
@@ -373,7 +439,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             ring_load_row<D, WS, LPP, const uint32_t*>(stg + li, stg + ri, stg + ri + one, rw);
         }
     };
-    auto step = [&](auto Kc, const RowRegs<D, WS, LPP>& rw, uint32_t (&Sr)[NRL], int& tsr) {
+    auto step = [&](auto Kc, auto SLc, const RowRegs<D, WS, LPP>& rw, uint32_t (&Sr)[NRL], int& tsr) {
         constexpr int K = decltype(Kc)::value;            // ring slot of row t: a compile-time register set
         using SetIn = std::integral_constant<int, (K + 1) & 1>;    // row t+3 goes where row t+1 was (W1 is even: K and t have the same parity)
         using SetOut = std::integral_constant<int, K & 1>;         // row t+2
@@ -385,10 +451,14 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
         const uint32_t told = ptr[KO * PPW + p];                  // prefix sum w rows back (0 while the window fills)
         ptr[K * PPW + p] = pt;
         tsr = (int)(pt - told);
-        const int sl_new = sl_cur == 0 ? 2 : sl_cur - 1;            // slot of row t+2 = (t + 2) mod 3
-        sl_cur = sl_cur == 2 ? 0 : sl_cur + 1;
         pin(Sr);
-        commit(SetOut{}, sl_new);
+        if constexpr (C::STATIC_SLOTS) {
+            commit(SetOut{}, std::integral_constant<int, (decltype(SLc)::value + 2) % 4>{});   // row t+2
+        } else {
+            const int sl_new = sl_cur == 0 ? 2 : sl_cur - 1;        // slot of row t+2 = (t + 2) mod 3
+            sl_cur = sl_cur == 2 ? 0 : sl_cur + 1;
+            commit(SetOut{}, sl_new);
+        }
     };
 
     // One trip of the outer loop = whole rounds of the ring AND whole row groups (TRIP rows), unrolled: every row step has
@@ -404,10 +474,11 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             ring_for_rows(std::make_integer_sequence<int, RPG>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 RowRegs<D, WS, LPP> rw;
-                lds_row(rw);
+                using SL = std::integral_constant<int, (U + R) % 4>;    // (static slots: TRIP % 4 == 0, so t % 4 == (U + R) % 4)
+                lds_row(SL{}, rw);
                 RING_STAMP(1);                                      // LDS reads of the row (the stamp waits for them)
                 int tsr;
-                step(std::integral_constant<int, (U + R) % W1>{}, rw, S[R], tsr);
+                step(std::integral_constant<int, (U + R) % W1>{}, SL{}, rw, S[R], tsr);
                 tsum = (R == 0 || h == R) ? tsr : tsum;             // the texture sum of the row this lane owns
                 RING_STAMP(2);
                 if constexpr (SPLIT && RING_ABL == 0) {
@@ -579,6 +650,7 @@ static bool ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
 {
     using C = RingCfg<D, WS, LPP>;
     RingGeom rg;
+    rg.rdelta = (uint32_t)(Rp.base - Lp.base);       // (launch_search_ring has checked that it fits)
     ring_range(g, &rg.x0, &rg.nx);
     const int rem = g.w - 4 * (C::NP - 1);
     rg.lastmask = rem >= 4 ? 0xffffffffu : ((1u << (8 * rem)) - 1u);
@@ -643,6 +715,12 @@ bool launch_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const B
                         bool fuse_border)
 {
     const int lpp = ring_lpp(g);
+    // the kernel addresses both planes from the left plane's rows with 32-bit lane offsets: they must be one allocation, the
+    // right plane behind the left one, with the same strides (rtdm_api.hip allocates them that way)
+    if (RING_DIRECT_LOADS && !(Rp.base > Lp.base && (size_t)(Rp.base - Lp.base) < ((size_t)1 << 32) - ((size_t)1 << 20) && Rp.pitch == Lp.pitch && Rp.frame == Lp.frame)) {
+        launch_search_fast(Lp, Rp, disp, cost, g, n, stream, fuse_border, 0);
+        return fuse_border;
+    }
 #define X(DD, WW, LL) if (g.D == DD && g.w == WW && lpp == LL) return ring_launch_one<DD, WW, LL>(Lp, Rp, disp, cost, g, n, stream, strips_hint, fuse_border);
     RTDM_RING_TABLE(X)
 #undef X

@@ -188,8 +188,10 @@ int rtdm_bm_create(const rtdm_bm_params* params, int max_width, int max_height, 
     const size_t px = (size_t)((max_width + 7) & ~7) * max_height * max_batch;
     hipError_t e = hipStreamCreateWithFlags(&bm->stream, hipStreamNonBlocking);
     // + slack: the search kernels stage whole dwords of whole tiles and may read past the last row's end
-    if (e == hipSuccess) e = hipMalloc((void**)&bm->dLp, plane + 1024);
-    if (e == hipSuccess) e = hipMalloc((void**)&bm->dRp, plane + 1024);
+    // (one allocation, the right planes behind the left ones: k_search_ring addresses both from the left plane's rows)
+    const size_t plane_al = (plane + 1024 + 255) & ~(size_t)255;
+    if (e == hipSuccess) e = hipMalloc((void**)&bm->dLp, 2 * plane_al);
+    if (e == hipSuccess) bm->dRp = bm->dLp + plane_al;
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dInL, plane);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dInR, plane);
     if (e == hipSuccess) e = hipMalloc((void**)&bm->dOut, px * sizeof(int16_t));
@@ -270,7 +272,7 @@ void rtdm_bm_destroy(rtdm_bm* bm)
         if (bm->evD2H[k]) (void)hipEventDestroy(bm->evD2H[k]);
     }
     for (auto& ev : bm->pending) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-    void* bufs[] = {bm->dLp, bm->dRp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead, bm->dMask, bm->dDepth};
+    void* bufs[] = {bm->dLp, bm->dInL, bm->dInR, bm->dOut, bm->dCost, bm->dLabel, bm->dSize, bm->dRuns, bm->dRowCnt, bm->dHead, bm->dMask, bm->dDepth};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (bm->hStage) (void)hipHostFree(bm->hStage);
     if (bm->stream) (void)hipStreamDestroy(bm->stream);

@@ -96,7 +96,7 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
             const int dx = 4 * q + k;
             const int pk = min(max(g.rofs + j0 + dx, 0), Wc) - rbmin - 4 * aq[q];         // 0..7
             sv |= (dx < w ? (unsigned)pk : 0x0cu) << (8 * k);                              // 0x0c selects the constant 0
-            cm |= (dx < w ? (unsigned)g.cap : 0u) << (8 * k);
+            cm |= (dx < w ? (unsigned)(g.cap + PREFILTER_BIAS) : 0u) << (8 * k);            // (biased planes: rtdm_kernels.h)
         }
         sel[q] = sv; capm[q] = cm;
     }
@@ -147,7 +147,7 @@ __device__ __forceinline__ void border_body(unsigned char* smem, Plane8 Lp, Plan
 #pragma unroll
                             for (int k = 0; k < 4; ++k) {
                                 const int c = c0 + k;
-                                const uint32_t by = c < W ? r0[c] : (more && c - W < W) ? r1[c - W] : 0u;
+                                const uint32_t by = c < W ? r0[c] : (more && c - W < W) ? r1[c - W] : (uint32_t)PREFILTER_BIAS;   // (a zero of the oracle's plane)
                                 v |= by << (8 * k);
                             }
                         }

@@ -58,7 +58,13 @@ struct Plane8 {  // batch of 8-bit images: frame f, row y at base + f*frame + y*
 struct Plane8W { uint8_t* base; size_t pitch, frame; };
 struct Plane16W { int16_t* base; size_t pitch_e, frame_e; };  // strides in elements
 
-// K1: x-Sobel prefilter of n left and n right frames in one launch.
+// The internal prefiltered planes hold clamp(sobel) + cap + PREFILTER_BIAS: every byte is >= 1.  The packed search kernels
+// need that (v_mqsad_pk_u16_u8 skips ZERO reference bytes: that is how a window's unused tail bytes are masked), absolute
+// differences do not see a common offset, and the texture term becomes |p - (cap + PREFILTER_BIAS)|.  (Until round 3 every
+// search wave added the bias to each staged dword itself.)  cap <= 63: the bytes stay <= 127.
+static constexpr int PREFILTER_BIAS = 1;
+
+// K1: x-Sobel prefilter of n left and n right frames in one launch (writes biased values, see above).
 void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, int cap, int n,
                       hipStream_t stream);
 
