@@ -57,6 +57,9 @@
 #ifndef RING_DIRECT_LOADS // 1: a staged dword is ONE (unaligned) global load at uniform row base + lane offset, stored as it is; 0: two
 #define RING_DIRECT_LOADS 1 // aligned dwords per lane and row, shifted into place by v_alignbyte
 #endif
+#ifndef RING_B64REC       // 1: D = 64 writes / reads its selection records in 8-byte pieces (34-dword stride: four workgroups per CU at (64, 9, 4))
+#define RING_B64REC 1
+#endif
 #ifndef RING_MINREC96     // 1: GroupSelectRec at D = 96 too (records of 240 instead of 208 bytes)
 #define RING_MINREC96 1
 #endif
@@ -118,7 +121,9 @@ struct RingCfg {
     // with eight rows per group: 64 records of 304 bytes would leave one workgroup per CU.
     static constexpr bool MINREC = SPLIT && RING_MINREC && !(D == 128 && RPG == 8) && !(D == 96 && !RING_MINREC96);
     static_assert(RPG == LPP || MINREC, "GroupSelect's lane reductions need one owner per lane of a pixel");
-    using Rec = SelRecord<D, MINREC || !SPLIT>;
+    // D = 64: records in 8-byte pieces at a 34-dword stride (rtdm_select.h)
+    static constexpr bool B64 = MINREC && D == 64 && RING_B64REC;
+    using Rec = SelRecord<D, MINREC || !SPLIT, B64>;
     static constexpr int NP = (WS + 3) / 4;        // 4-byte pieces of a window row
     static constexpr int W1 = WS + 1;              // ring slots
     static constexpr int PPW = 64 / LPP;           // pixels (columns) per wave
@@ -137,12 +142,12 @@ struct RingCfg {
     // slot of every unrolled step a constant (one item per row only: ds_read2's 8-bit dword offsets must reach the slots)
     static constexpr bool STATIC_SLOTS = RING_STATIC_SLOTS && ITEMS == 1 && TRIP % 4 == 0;
     static constexpr int NSLOT = STATIC_SLOTS ? 4 : 3;
-    static constexpr int STG = (NSLOT * SLOT + W1 * PPW + 3) & ~3;  // dwords per wave: staged rows + the texture prefix ring
+    static constexpr int STG = (NSLOT * SLOT + W1 * PPW / 2 + 3) & ~3;  // dwords per wave: staged rows + the texture prefix ring (u16)
     static constexpr int WAVE_LDS = STG + PPW * RPG * Rec::DWORDS;   // + the selection's records, one per owner lane (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
     // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
-    static constexpr int WAVES = LPP >= 8 ? 2 : LPP == 4 ? (RING_REGS <= 64 ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : (RING_REGS <= 72 && NRL <= 8) ? 4 : RING_REGS <= 112 ? 3 : 2;
+    static constexpr int WAVES = LPP >= 8 ? 2 : LPP == 4 ? (RING_REGS <= (MINREC ? 80 : 64) ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : (RING_REGS <= 72 && NRL <= 8) ? 4 : RING_REGS <= 112 ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
     // border-column workgroups may ride in this kernel's grid (small launches); not in the four-wave forms, whose 128
     // registers the border body's code would overflow
@@ -279,19 +284,23 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     if (ys0 >= ys1) return;
     const int r = g.r;
     const uint8_t* Lb = Lp.base + (size_t)f * Lp.frame;
+#if !RING_DIRECT_LOADS
     const uint8_t* Rb = Rp.base + (size_t)f * Rp.frame;
+#endif
     const int Lbase = g.lofs + x_tile - r + phi;   // image column of byte 0 of this wave's copy (left)
     const int Rbase = g.rofs + x_tile - r + phi;   //                                            (right)
     const uint32_t capb = (uint32_t)(g.cap + PREFILTER_BIAS) * 0x01010101u;
 
     uint32_t* stg = lds + phi * C::WAVE_LDS;       // this wave's slice: nothing below is shared between waves
-    uint32_t* ptr = stg + C::NSLOT * SLOT;         // texture prefix ring [W1][PPW] (the lanes of a pixel write the same value)
+    // texture prefix ring [W1][PPW], 16 bits each (the lanes of a pixel write the same value; window sums are < 2^16 and
+    // differences of prefix sums are taken modulo 2^16, so the prefix sums themselves may wrap)
+    unsigned short* ptr = (unsigned short*)(stg + C::NSLOT * SLOT);
     const bool owner = RPG == LPP || h < RPG;       // this lane owns row h of every group
     uint32_t* scr = stg + C::STG + (owner ? lane : 0) * RECD;        // this lane's selection record (lanes that own nothing: never used)
     uint32_t* scr_w = stg + C::STG + p * RECD + h * NRL;             // SPLIT: where this lane's slice of the group's first row goes
-    using GSel = std::conditional_t<MINREC, GroupSelectRec<D, LPP>, GroupSelect<D, LPP>>;
+    using GSel = std::conditional_t<MINREC, GroupSelectRec<D, LPP, C::B64>, GroupSelect<D, LPP>>;
     unsigned short* scr_m = (unsigned short*)(stg + C::STG + p * RECD + D / 2) + h * (NRL / 4);   // ... and the minima of its groups
-    if constexpr (MINREC) GroupSelectRec<D, LPP>::init(scr);
+    if constexpr (MINREC) GSel::init(scr);
 
     // --- staging: item idx = one dword of the wave's copy; dword m holds copy bytes [4m, 4m+4) (biased planes) ---------
     // Unconditional loads: bytes past a row's end only ever reach lanes that are not `active`, and the prefiltered planes
@@ -449,8 +458,8 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
         constexpr int KO = (K + 1) % W1;
         pt += tnew;
         const uint32_t told = ptr[KO * PPW + p];                  // prefix sum w rows back (0 while the window fills)
-        ptr[K * PPW + p] = pt;
-        tsr = (int)(pt - told);
+        ptr[K * PPW + p] = (unsigned short)pt;
+        tsr = (int)((pt - told) & 0xffffu);
         pin(Sr);
         if constexpr (C::STATIC_SLOTS) {
             commit(SetOut{}, std::integral_constant<int, (decltype(SLc)::value + 2) % 4>{});   // row t+2

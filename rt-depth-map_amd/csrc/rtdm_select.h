@@ -159,9 +159,12 @@ __device__ __forceinline__ int select_disparity(const uint32_t (&rr)[D / 2], int
 // eight consecutive lanes' 16-byte stores start in eight different bank quads: 12, 20, 28, 36 dwords for D = 16 .. 64 (the
 // minima fill what used to be padding), 60 / 76 / 108 / 148 for D = 96 / 128 / 192 / 256
 // (MINIMA = false, GroupSelect at D = 96 / 128: D/2 + 4 = 52 / 68 dwords)
-template <int D, bool MINIMA = true> struct SelRecord {
+// B64: the record is written and read in 8-byte pieces instead (GroupSelectRec): the stride only has to be an odd number of
+// 8-byte pairs -- 34 dwords at D = 64, which is what lets four workgroups of k_search_ring<64, 9, 4> share a CU's 160 KB.
+template <int D, bool MINIMA = true, bool B64 = false> struct SelRecord {
     static constexpr int QUADS = MINIMA ? (D / 2 + D / 16 + 3) / 4 : D / 8 + 1;
-    static constexpr int DWORDS = 4 * (QUADS | 1);
+    static constexpr int PAIRS = (D / 2 + D / 16 + 1) / 2;
+    static constexpr int DWORDS = B64 ? 2 * (PAIRS | 1) : 4 * (QUADS | 1);
 };
 template <int D>
 __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2], int tsum, const BMGeom& g, uint32_t* scr,
@@ -431,18 +434,35 @@ struct GroupSelect {
 // evaluates test (A) itself as a second sum identity over those minima (8 packed instructions against a 9-instruction
 // broadcast of T+1, 16 compares in the other lanes and a 10-instruction reduction).  Per 64 pixel-rows at D = 64, four lanes per pixel: about 45 VALU instructions
 // and 12 registers of per-group state (mm, kpart) less.  Same results: the tests (A) and (B) of GroupSelect, same values.
-template <int D, int LPP>
+template <int D, int LPP, bool B64 = false>
 struct GroupSelectRec {
     static constexpr int NRL = D / (2 * LPP), NGH = NRL / 4, NG = D / 8, NGD = NG / 2, NGQ = (NGD + 3) / 4;
-    static_assert(D % 16 == 0 && D / 2 + 4 * NGQ <= SelRecord<D>::DWORDS, "the minima live behind the SADs of the record");
+    static_assert(D % 16 == 0 && D / 2 + (B64 ? 2 * ((NGD + 1) / 2) : 4 * NGQ) <= SelRecord<D, true, B64>::DWORDS, "the minima live behind the SADs of the record");
     static_assert(NRL % 4 == 0, "a lane's slice must be whole groups of eight disparities");
     typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    // four dwords of a record at a 16-byte (8-byte if B64) aligned offset
+    static __device__ __forceinline__ u4 ld4(const uint32_t* q)
+    {
+        if constexpr (B64) { const u2 a = *(const u2*)q, b = *(const u2*)(q + 2); return u4{a[0], a[1], b[0], b[1]}; }
+        else return *(const u4*)q;
+    }
+    static __device__ __forceinline__ void st4(uint32_t* q, u4 v)
+    {
+        if constexpr (B64) { *(u2*)q = u2{v[0], v[1]}; *(u2*)(q + 2) = u2{v[2], v[3]}; }
+        else *(u4*)q = v;
+    }
 
     // once per kernel: unused minima slots of this lane's record never win and never count
     static __device__ __forceinline__ void init(uint32_t* rec_own)
     {
+        if constexpr (B64) {
 #pragma unroll
-        for (int i = 0; i < NGQ; ++i) *(u4*)(rec_own + D / 2 + 4 * i) = u4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            for (int i = 0; i < (NGD + 1) / 2; ++i) *(u2*)(rec_own + D / 2 + 2 * i) = u2{0xffffffffu, 0xffffffffu};
+        } else {
+#pragma unroll
+            for (int i = 0; i < NGQ; ++i) *(u4*)(rec_own + D / 2 + 4 * i) = u4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        }
     }
 
     // row R of the group: sv = this lane's slice of its window sums; wr = where the slice goes in the record of the row's
@@ -451,7 +471,7 @@ struct GroupSelectRec {
     __device__ __forceinline__ void row(const uint32_t (&sv)[NRL], uint32_t* wr, unsigned short* wm)
     {
 #pragma unroll
-        for (int i = 0; i < NRL; i += 4) *(u4*)(wr + i) = u4{sv[i], sv[i + 1], sv[i + 2], sv[i + 3]};
+        for (int i = 0; i < NRL; i += 4) st4(wr + i, u4{sv[i], sv[i + 1], sv[i + 2], sv[i + 3]});
 #pragma unroll
         for (int gq = 0; gq < NGH; ++gq) {
             const uint32_t m = sel_pk_min(sel_pk_min(sv[4 * gq], sv[4 * gq + 1]), sel_pk_min(sv[4 * gq + 2], sv[4 * gq + 3]));
@@ -465,7 +485,13 @@ struct GroupSelectRec {
         uint32_t mn[4 * NGQ];                                        // minima of the groups 2q (low half) and 2q + 1 (high half)
 #pragma unroll
         for (int i = 0; i < NGQ; ++i) {
-            const u4 v = *(const u4*)(rec_own + D / 2 + 4 * i);
+            // (B64 with an odd number of minima pairs: the last two dwords lie past the record's end -- the neighbour's
+            //  first SADs or, behind the last record, nothing that is read: they are never used, NGD counts the real ones)
+            u4 v;
+            if constexpr (B64 && (NGD % 4 == 1 || NGD % 4 == 2)) {
+                if (i == NGQ - 1) { const u2 a = *(const u2*)(rec_own + D / 2 + 4 * i); v = u4{a[0], a[1], 0xffffffffu, 0xffffffffu}; }
+                else v = ld4(rec_own + D / 2 + 4 * i);
+            } else v = ld4(rec_own + D / 2 + 4 * i);
             mn[4 * i] = v[0]; mn[4 * i + 1] = v[1]; mn[4 * i + 2] = v[2]; mn[4 * i + 3] = v[3];
         }
         uint32_t kk[2] = {0xffffffffu, 0xffffffffu};
@@ -479,7 +505,7 @@ struct GroupSelectRec {
         const uint32_t kmin = min(kk[0], kk[1]);
         const int m1 = (int)(kmin >> 8);
         const int gs = (int)(kmin & 0xffu);
-        const u4 grp = *(const u4*)(rec_own + 4 * gs);               // the four registers of the winning group
+        const u4 grp = ld4(rec_own + 4 * gs);                        // the four registers of the winning group
         // (A) as a sum identity too: sum over ALL groups of max(T+1 - group minimum, 0) must equal what the winner's group and
         // the neighbour's group contribute -- any other group with a minimum <= T adds a positive term.  Groups 2q / 2q+1
         // sit in the low / high halves, so the (adjacent) winner and neighbour groups fall into different halves: a half that
@@ -515,7 +541,7 @@ struct GroupSelectRec {
             // the group a-1 or a+1 falls into, if that is not the winner's
             const int nbq = (e == 0 && has_n) ? gs - 1 : (e == 7 && has_p) ? gs + 1 : gs;
             const bool has_nb = nbq != gs;
-            const u4 nbg = *(const u4*)(rec_own + 4 * nbq);
+            const u4 nbg = ld4(rec_own + 4 * nbq);
             const uint32_t nbmin = sv[D + nbq];                      // its minimum, from the minima behind the SADs
             const uint32_t T1pk = T1 * 0x00010001u, nbmask = has_nb ? 0xffffffffu : 0u;
             uint32_t zz[4];
