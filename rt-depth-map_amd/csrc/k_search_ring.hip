@@ -142,7 +142,8 @@ struct RingCfg {
     // slot of every unrolled step a constant (one item per row only: ds_read2's 8-bit dword offsets must reach the slots)
     static constexpr bool STATIC_SLOTS = RING_STATIC_SLOTS && ITEMS == 1 && TRIP % 4 == 0;
     static constexpr int NSLOT = STATIC_SLOTS ? 4 : 3;
-    static constexpr int STG = (NSLOT * SLOT + W1 * PPW / 2 + 3) & ~3;  // dwords per wave: staged rows + the texture prefix ring (u16)
+    // dwords per wave: staged rows + the texture prefix ring [W1][PPW] + the window texture sums of a group's rows [RPG][PPW] (u16)
+    static constexpr int STG = (NSLOT * SLOT + (W1 + RPG) * PPW / 2 + 3) & ~3;
     static constexpr int WAVE_LDS = STG + PPW * RPG * Rec::DWORDS;   // + the selection's records, one per owner lane (rtdm_select.h)
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
@@ -295,7 +296,11 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
     // texture prefix ring [W1][PPW], 16 bits each (the lanes of a pixel write the same value; window sums are < 2^16 and
     // differences of prefix sums are taken modulo 2^16, so the prefix sums themselves may wrap)
     unsigned short* ptr = (unsigned short*)(stg + C::NSLOT * SLOT);
+    // the window texture sum of row R of a group goes to ptw[R][p] (every lane of the pixel writes the same 16 bits) and the
+    // row's owner reads its own at the end of the group: no per-row select in registers
+    unsigned short* ptw = ptr + W1 * PPW;
     const bool owner = RPG == LPP || h < RPG;       // this lane owns row h of every group
+    const unsigned short* ptw_own = ptw + (owner ? h : 0) * PPW + p;
     uint32_t* scr = stg + C::STG + (owner ? lane : 0) * RECD;        // this lane's selection record (lanes that own nothing: never used)
     uint32_t* scr_w = stg + C::STG + p * RECD + h * NRL;             // SPLIT: where this lane's slice of the group's first row goes
     using GSel = std::conditional_t<MINREC, GroupSelectRec<D, LPP, C::B64>, GroupSelect<D, LPP>>;
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             ring_load_row<D, WS, LPP, const uint32_t*>(stg + li, stg + ri, stg + ri + one, rw);
         }
     };
-    auto step = [&](auto Kc, auto SLc, const RowRegs<D, WS, LPP>& rw, uint32_t (&Sr)[NRL], int& tsr) {
+    auto step = [&](auto Kc, auto SLc, auto Rc, const RowRegs<D, WS, LPP>& rw, uint32_t (&Sr)[NRL]) {
         constexpr int K = decltype(Kc)::value;            // ring slot of row t: a compile-time register set
         using SetIn = std::integral_constant<int, (K + 1) & 1>;    // row t+3 goes where row t+1 was (W1 is even: K and t have the same parity)
         using SetOut = std::integral_constant<int, K & 1>;         // row t+2
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
         pt += tnew;
         const uint32_t told = ptr[KO * PPW + p];                  // prefix sum w rows back (0 while the window fills)
         ptr[K * PPW + p] = (unsigned short)pt;
-        tsr = (int)((pt - told) & 0xffffu);
+        ptw[decltype(Rc)::value * PPW + p] = (unsigned short)(pt - told);   // (mod 2^16: the window sum itself is < 2^16)
         pin(Sr);
         if constexpr (C::STATIC_SLOTS) {
             commit(SetOut{}, std::integral_constant<int, (decltype(SLc)::value + 2) % 4>{});   // row t+2
@@ -479,16 +484,13 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             if (t >= nstepsg) return false;
             RING_STAMP(0);                                          // (loop overhead + whatever precedes the group)
             GSel gsel;
-            int tsum = 0;
             ring_for_rows(std::make_integer_sequence<int, RPG>{}, [&](auto Rc) {
                 constexpr int R = decltype(Rc)::value;
                 RowRegs<D, WS, LPP> rw;
                 using SL = std::integral_constant<int, (U + R) % 4>;    // (static slots: TRIP % 4 == 0, so t % 4 == (U + R) % 4)
                 lds_row(SL{}, rw);
                 RING_STAMP(1);                                      // LDS reads of the row (the stamp waits for them)
-                int tsr;
-                step(std::integral_constant<int, (U + R) % W1>{}, SL{}, rw, S[R], tsr);
-                tsum = (R == 0 || h == R) ? tsr : tsum;             // the texture sum of the row this lane owns
+                step(std::integral_constant<int, (U + R) % W1>{}, SL{}, Rc, rw, S[R]);
                 RING_STAMP(2);
                 if constexpr (SPLIT && RING_ABL == 0) {
                     // the row's slice goes to its owner's record and into the group minima at once: S[R] is dead after this
@@ -505,6 +507,7 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
             dofs += dstep; cofs += cstep;
             // Selection is skipped for a wave none of whose pixels can produce a disparity here (untextured, outside the
             // tile, masked): exact, such a pixel is FILTERED and writes no cost whatever its SADs are.
+            const int tsum = *ptw_own;                               // the texture sum of the row this lane owns
             const bool dead = !active || !row_ok || masked_col || tsum < g.tex;
             if (__builtin_amdgcn_ballot_w64(!dead) == 0) {
                 if (active && row_ok) *(int16_t*)(db + dof) = (int16_t)g.filtered;

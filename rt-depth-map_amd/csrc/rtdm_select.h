@@ -28,16 +28,18 @@ __device__ __forceinline__ uint32_t sel_pk_sub_sat(uint32_t a, uint32_t b)
 __device__ __forceinline__ uint32_t sel_pk_add_sat(uint32_t a, uint32_t b)
 { return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(sel_us2, a), __builtin_bit_cast(sel_us2, b))); }
 
-__device__ __forceinline__ int sel_div_trunc(int num, int den)   // den > 0, |num| < 2^24
+// The sub-pixel term of A.3b, trunc((p - n) * 256 / den) with den = p + n - 2 m + |p - n| (0 if den == 0), for m <= min(p, n):
+// den = 2 (max(p, n) - m) and |p - n| <= max(p, n) - m, so the magnitude is floor(|p - n| * 128 / u) <= 128 with
+// u = max(p, n) - m -- one float estimate (both operands < 2^22: exact) and one correction each way, no branches.
+__device__ __forceinline__ int sel_subpixel(int p, int n, int m)
 {
-    const unsigned an = (unsigned)(num < 0 ? -num : num);
-    unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)den));
-    // an, den < 2^24 are exact in float; rcp and the product are each within an ulp, so for quotients below 2^15 (here
-    // |num / den| <= 128) the estimate is off by less than one: one correction each way is enough
-    const int rem = (int)an - (int)(q * (unsigned)den);
-    if (rem < 0) --q;
-    else if (rem >= den) ++q;
-    return num < 0 ? -(int)q : (int)q;
+    const int hi = max(p, n), lo = min(p, n);
+    const unsigned an = (unsigned)(hi - lo) << 7, u = (unsigned)max(hi - m, 1);      // (u = 0 only with |p - n| = 0: quotient 0 either way)
+    unsigned q = (unsigned)((float)an * __builtin_amdgcn_rcpf((float)u));
+    const int rem = (int)an - (int)(q * u);
+    q += (unsigned)(rem >= (int)u);
+    q += (unsigned)(rem >> 31);                                                        // -1 if the estimate was one too large
+    return p < n ? -(int)q : (int)q;
 }
 
 // Returns the x16 disparity (g.filtered if rejected); *minsad = the winning SAD, *rejected = the pixel failed a test.
@@ -137,17 +139,12 @@ __device__ __forceinline__ int select_disparity(const uint32_t (&rr)[D / 2], int
         fail |= (even ? zlo : zhi) != wsame;
         fail |= (even ? zhi : zlo) != wother;
     }
-    int out = g.filtered;
-    if (!fail) {
-        const int pp = has_p ? p_real : n_real;
-        const int nn = has_n ? n_real : p_real;
-        const int den = pp + nn - 2 * m1 + abs(pp - nn);
-        const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
-        out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
-    }
+    const int pp = has_p ? p_real : n_real;
+    const int nn = has_n ? n_real : p_real;
+    const int out = ((D - a - 1 + g.minD) * 256 + sel_subpixel(pp, nn, m1) + 15) >> 4;
     *minsad = m1;
     *rejected = fail;
-    return out;
+    return fail ? g.filtered : out;
 }
 
 // The same selection with the data-dependent register fetches done through LDS: the D values are written once to the
@@ -233,17 +230,12 @@ __device__ __forceinline__ int select_disparity_lds(const uint32_t (&rr)[D / 2],
         const uint32_t want = term(m1) + (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
         fail |= z != want;
     }
-    int out = g.filtered;
-    if (!fail) {
-        const int pp = has_p ? p_real : n_real;
-        const int nn = has_n ? n_real : p_real;
-        const int den = pp + nn - 2 * m1 + abs(pp - nn);
-        const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
-        out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
-    }
+    const int pp = has_p ? p_real : n_real;
+    const int nn = has_n ? n_real : p_real;
+    const int out = ((D - a - 1 + g.minD) * 256 + sel_subpixel(pp, nn, m1) + 15) >> 4;
     *minsad = m1;
     *rejected = fail;
-    return out;
+    return fail ? g.filtered : out;
 }
 
 // ---- selection for pixels whose D values are spread over LPP lanes (k_search_ring), without transposing them --------
@@ -412,17 +404,12 @@ struct GroupSelect {
             const uint32_t want = term(m1) + (has_n ? term(n_real) : 0u) + (has_p ? term(p_real) : 0u);
             fail |= (z != want) | (cnt != expect);
         }
-        int out = g.filtered;
-        if (!fail) {
-            const int pp = has_p ? p_real : n_real;
-            const int nn = has_n ? n_real : p_real;
-            const int den = pp + nn - 2 * m1 + abs(pp - nn);
-            const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
-            out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
-        }
+        const int pp = has_p ? p_real : n_real;
+        const int nn = has_n ? n_real : p_real;
+        const int out = ((D - a - 1 + g.minD) * 256 + sel_subpixel(pp, nn, m1) + 15) >> 4;
         *minsad = m1;
         *rejected = fail;
-        return out;
+        return fail ? g.filtered : out;
     }
 };
 
@@ -534,8 +521,8 @@ struct GroupSelectRec {
         const int a = 8 * gs + e;
         const bool has_n = a > 0, has_p = a + 1 < D;
         const unsigned short* sv = (const unsigned short*)rec_own;
-        const int n_real = sv[has_n ? a - 1 : a];
-        const int p_real = sv[has_p ? a + 1 : a];
+        const int n_real = sv[max(a - 1, 0)];                        // (sad[a] itself where the neighbour does not exist)
+        const int p_real = sv[min(a + 1, D - 1)];
         bool fail = tsum < g.tex;
         if (g.uniq > 0) {
             // the group a-1 or a+1 falls into, if that is not the winner's
@@ -558,17 +545,13 @@ struct GroupSelectRec {
             const uint32_t wantg = tm1 + (has_nb ? term((int)nbmin) : 0u);                             // (A): over the group minima
             fail |= (z + zg) != (want + wantg);                      // z >= want and zg >= wantg: equal sums <=> both equal
         }
-        int out = g.filtered;
-        if (!fail) {
-            const int pp = has_p ? p_real : n_real;
-            const int nn = has_n ? n_real : p_real;
-            const int den = pp + nn - 2 * m1 + abs(pp - nn);
-            const int q = den != 0 ? sel_div_trunc((pp - nn) * 256, den) : 0;
-            out = ((D - a - 1 + g.minD) * 256 + q + 15) >> 4;
-        }
+        // sad[-1] := sad[1], sad[D] := sad[D-2] (A.3b): the missing neighbour takes the other one's value
+        const int pp = has_p ? p_real : n_real;
+        const int nn = has_n ? n_real : p_real;
+        const int out = ((D - a - 1 + g.minD) * 256 + sel_subpixel(pp, nn, m1) + 15) >> 4;
         *minsad = m1;
         *rejected = fail;
-        return out;
+        return fail ? g.filtered : out;
     }
 };
 
