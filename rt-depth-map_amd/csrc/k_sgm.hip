@@ -223,9 +223,16 @@ __device__ __forceinline__ void st_pack(uint16_t* p, const int* l)
     else { for (int j = 0; j < NPL; ++j) p[j] = (uint16_t)l[j]; }
 }
 
-template <int NPL, int PF>
+// LAST (the last direction of a frame): the aggregated costs min(S + L_r, 32767) of a pixel are complete the moment this
+// wave has them in its lanes, so the winner-take-all step of k_sgm_select runs right here -- wave minimum of S << 8 | d,
+// uniqueness vote, S[d* +- 1] by v_readlane, quadratic sub-pixel in lane 0 -- and S is neither written back nor read again
+// (424 MB of HBM traffic per 720p D = 128 pair, and the select kernel's launch).  What leaves is 8 bytes per pixel:
+// {x16 disparity or INV, integer winner + minD or minD - 1, minimum cost, 0} for k_sgm_lrfinal.
+struct SgmWin { int16_t d16, bd; uint16_t mins, pad; };
+
+template <int NPL, int PF, bool LAST>
 __global__ __launch_bounds__(256) void k_sgm_path_w(const uint16_t* C, uint16_t* S, SGMGeom g, int dx, int dy, int P1, int P2,
-                                                    int first_dir, int nlines)
+                                                    int first_dir, int nlines, SgmWin* win, int uniq)
 {
     const int lane = threadIdx.x & 63;
     const int line = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -283,11 +290,41 @@ __global__ __launch_bounds__(256) void k_sgm_path_w(const uint16_t* C, uint16_t*
 #pragma unroll
                 for (int j = 0; j < NPL; ++j) l[j] = nl[j];
             }
-            if (live) {
-                int o[NPL];
+            int o[NPL];
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) o[j] = first_dir ? l[j] : min((int)sv.v[j] + l[j], 32767);   // R5: saturating sum
-                st_pack<NPL>(sp + (long)step * stride, o);
+            for (int j = 0; j < NPL; ++j) o[j] = first_dir ? l[j] : min((int)sv.v[j] + l[j], 32767);   // R5: saturating sum
+            if constexpr (!LAST) {
+                if (live) st_pack<NPL>(sp + (long)step * stride, o);
+            } else {
+                // winner-take-all on the finished pixel (k_sgm_select's first half, lanes = NPL consecutive disparities each)
+                unsigned key = 0x7fffffffu;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) if (live) key = min(key, ((unsigned)o[j] << 8) | (unsigned)(d0 + j));
+                key = (unsigned)wave_min_i32((int)key);              // keys are < 2^24: the signed minimum is fine
+                const int mins = (int)(key >> 8), bd = (int)(key & 0xffu);
+                bool hit = false;
+                const int lim = mins * 100;
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) hit |= live && abs(d0 + j - bd) > 1 && o[j] * (100 - uniq) < lim;
+                const int xi = sx + step * dx, yy = sy + step * dy;
+                SgmWin wv;
+                wv.d16 = (int16_t)((g.minD - 1) * 16); wv.bd = (int16_t)(g.minD - 1); wv.mins = 0; wv.pad = 0;
+                if (!__any(hit)) {                                    // wave-uniform
+                    const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
+                    int s_p = 0, s_n = 0;
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {
+                        if (ip % NPL == j) s_p = __builtin_amdgcn_readlane(o[j], ip / NPL);
+                        if (in % NPL == j) s_n = __builtin_amdgcn_readlane(o[j], in / NPL);
+                    }
+                    int d16 = bd * 16;
+                    if (bd > 0 && bd < D - 1) {
+                        const int den = max(s_n + s_p - 2 * mins, 1);
+                        d16 += div_trunc_rcp((s_n - s_p) * 16 + den, den * 2);        // |numerator| < 2^21
+                    }
+                    wv.d16 = (int16_t)(d16 + g.minD * 16); wv.bd = (int16_t)(bd + g.minD); wv.mins = (uint16_t)mins;
+                }
+                if (lane == 0) win[((size_t)blockIdx.y * H + yy) * W1 + xi] = wv;
             }
             int m = l[0];
 #pragma unroll
@@ -402,6 +439,44 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
     }
 }
 
+// The second half of k_sgm_select for winners that were found inside the last path pass (k_sgm_path_w<.., LAST>): the votes
+// of a row (R7), the always-on left-right check (R9) and the row's x16 disparities.  One workgroup per row.
+__global__ __launch_bounds__(256) void k_sgm_lrfinal(const SgmWin* win, Plane16W disp, SGMGeom g, int disp12MaxDiff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long* key = (unsigned long long*)smem;     // W : (minS << 32 | 0xffff - x) votes per right column
+    int16_t* bdv = (int16_t*)(key + g.W);                    // W : integer winner + minD of column x (or minD-1)
+    int16_t* row = bdv + g.W;                                // W : disparity row
+    const int y = blockIdx.y, f = blockIdx.z;
+    const int W = g.W, minD = g.minD, INV = (minD - 1) * 16;
+    for (int x = threadIdx.x; x < W; x += 256) { key[x] = ~0ull; bdv[x] = (int16_t)(minD - 1); row[x] = (int16_t)INV; }
+    __syncthreads();
+    const SgmWin* wrow = win + ((size_t)f * g.H + y) * g.W1;
+    for (int xi = threadIdx.x; xi < g.W1; xi += 256) {
+        const SgmWin w = wrow[xi];
+        if (w.bd < minD) continue;                            // rejected by the uniqueness test: no vote, INV
+        const int x = g.x0 + xi, x2 = x - (int)w.bd;
+        if (x2 >= 0 && x2 < W) atomicMin(&key[x2], ((unsigned long long)w.mins << 32) | (unsigned)(0xffff - x));
+        bdv[x] = w.bd;
+        row[x] = w.d16;
+    }
+    __syncthreads();
+    int16_t* out = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+    for (int x = threadIdx.x; x < W; x += 256) {
+        int d1 = row[x];
+        if (d1 != INV) {                                      // R9: always on (the host passes disp12MaxDiff > 0 ? it : 1)
+            const int da = d1 >> 4, db = (d1 + 15) >> 4;
+            const int xa = x - da, xb = x - db;
+            const auto vote = [&](int xv) -> int { return key[xv] != ~0ull ? (int)bdv[0xffff - (unsigned)(key[xv] & 0xffffu)] : INV; };
+            bool ba = false, bb = false;
+            if (xa >= 0 && xa < W) { const int v = vote(xa); ba = v >= minD && abs(v - da) > disp12MaxDiff; }
+            if (xb >= 0 && xb < W) { const int v = vote(xb); bb = v >= minD && abs(v - db) > disp12MaxDiff; }
+            if (ba && bb) d1 = INV;
+        }
+        out[x] = (int16_t)d1;
+    }
+}
+
 // R10: medianBlur(disp, disp, 3) -- 3x3 median of the int16 map with clamped coordinates -- followed by the speckle
 // filter's per-row init on the filtered row.  One workgroup per row; the three source rows stream through L2.
 __device__ __forceinline__ void mnmx(int& a, int& b) { const int t = min(a, b); b = max(a, b); a = t; }
@@ -468,6 +543,11 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     if (g.D % npl) npl = 4;
     static const int wave_paths = env_int("RTDM_SGM_WAVE_PATHS", 1);
     const bool aligned = (((size_t)b.C | (size_t)b.S) & 7) == 0;
+    // RTDM_SGM_FUSE_SELECT=0 (A/B): the last direction writes S like the others and k_sgm_select reads it back
+    static const int fuse_env = env_int("RTDM_SGM_FUSE_SELECT", 1);
+    const bool fuse_select = fuse_env && wave_paths && aligned && g.D <= 256;
+    const int last_dir = paths == 5 ? 5 : 7;
+    SgmWin* win = (SgmWin*)b.gr;                     // the right image's bounds are dead once the pixel costs exist: 8 bytes per pixel
     for (int k = 0; k < 8; ++k) {
         const int dx = dirs[k][0], dy = dirs[k][1];
         if (paths == 5 && dy < 0) continue;          // MODE_SGBM's five directions: nothing runs upwards
@@ -475,12 +555,16 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
         if (wave_paths && aligned && g.D <= 256) {
             const dim3 wgrid((lines + 3) / 4, n);
             const int first = k == 0 ? 1 : 0;
+#define RTDM_PATHW(N, P) do { if (last) hipLaunchKernelGGL((k_sgm_path_w<N, P, true>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); \
+                              else hipLaunchKernelGGL((k_sgm_path_w<N, P, false>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); } while (0)
+            const bool last = fuse_select && k == last_dir;
             switch (npl) {
-                case 1: hipLaunchKernelGGL((k_sgm_path_w<1, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
-                case 2: hipLaunchKernelGGL((k_sgm_path_w<2, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
-                case 3: hipLaunchKernelGGL((k_sgm_path_w<3, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
-                default: hipLaunchKernelGGL((k_sgm_path_w<4, 8>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines); break;
+                case 1: RTDM_PATHW(1, 8); break;
+                case 2: RTDM_PATHW(2, 8); break;
+                case 3: RTDM_PATHW(3, 8); break;
+                default: RTDM_PATHW(4, 8); break;
             }
+#undef RTDM_PATHW
         } else {
             hipLaunchKernelGGL(k_sgm_path, dim3(lines, n), dim3(threads), 0, stream, b.C, b.S, g, dx, dy, P1, P2, k == 0 ? 1 : 0);
         }
@@ -490,7 +574,8 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     // select -> a temporary plane (the bounds buffer of the left image is free again), median -> the caller's plane
     int16_t* tmp = (int16_t*)b.gl;
     const Plane16W tplane{tmp, (size_t)g.W, (size_t)g.W * g.H};
-    launch_select<false>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, tplane, g, uniq, disp12MaxDiff, b, 0);
+    if (fuse_select) hipLaunchKernelGGL(k_sgm_lrfinal, dim3(1, g.H, n), blk, lds, stream, win, tplane, g, disp12MaxDiff);
+    else launch_select<false>((g.D + 63) / 64, dim3(1, g.H, n), lds, stream, b.S, tplane, g, uniq, disp12MaxDiff, b, 0);
     const size_t mlds = (size_t)g.W * 6;
     const int INV = (g.minD - 1) * 16;
     if (speckle) {
