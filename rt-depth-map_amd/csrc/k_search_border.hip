@@ -56,6 +56,7 @@ void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const
 {
     const int ncols = max(0, lx1 - lx0) + max(0, rx1 - rx0);
     if (ncols <= 0) return;
+    if (launch_search_border2(Lp, Rp, disp, cost, g, n, stream, lx0, lx1, rx0, rx1)) return;   // rows in the lanes: far fewer instructions
     BorderGeom bg;
     bg.lx0 = lx0; bg.lx1 = max(lx1, lx0); bg.rx0 = rx0; bg.rx1 = max(rx1, rx0);
     const int nrows = g.vy1 - g.vy0;

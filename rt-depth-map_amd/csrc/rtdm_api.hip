@@ -489,7 +489,9 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
             if (side) {
                 HIPC(hipEventRecord(ln.fork, s));
                 HIPC(hipStreamWaitEvent(ln.side, ln.fork, 0));
+#ifndef RTDM_DEBUG_SKIP_BORDER   // (timing-only variant build: what the border columns cost the search stage; outputs are wrong)
                 launch_search_border(Lpr, Rpr, disp, ln.dCost, g, n, ln.side, lx0, lx1, rx0, rx1);
+#endif
                 HIPC(hipEventRecord(ln.join, ln.side));
             }
             bool fused = fuse;

@@ -105,6 +105,10 @@ void fast_border_ranges(const BMGeom& g, int* lx0, int* lx1, int* rx0, int* rx1)
 bool border_search_supported(const BMGeom& g);
 void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n,
                           hipStream_t stream, int lx0, int lx1, int rx0, int rx1);
+// second form (k_search_border2.hip): one wave = one border column x 64 rows, rows in the lanes, disparities unrolled; 4-5x
+// fewer instructions per pixel.  Returns false (nothing launched) for what it does not cover; launch_search_border tries it first.
+bool launch_search_border2(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n,
+                           hipStream_t stream, int lx0, int lx1, int rx0, int rx1);
 
 // K3: row-local left-right consistency check (+ column masking to the valid rectangle).  With
 // label != nullptr the speckle filter's per-row init runs on the checked row in the same pass.
