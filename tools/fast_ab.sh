@@ -1,12 +1,14 @@
 #!/bin/bash
-# A/B of k_search_fast build variants on the large-D configurations (run on the GPU box): rebuilds the kernel with the given
-# flags and times the search stage of config 3 (d=128, 11x11) and of the reference's default (d=192, 13x13), checking the bytes.
+# A/B of k_search_fast build variants on the large-D configurations (run on the GPU box): each flag set is built as a VARIANT
+# library (`make variant`; the shipped library is never touched) and times the search stage of config 3 (d=128, 11x11) and of
+# d=192 / d=256 with RTDM_RING=0 (so that k_search_fast runs), checking the bytes.
 R=$GRAFT_REPO_ROOT
 cd $R/rt-depth-map_amd
+K=0
 for V in "$@"; do
-    F=$(echo "$V" | tr ',' ' ')
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result $F -c csrc/k_search_fast.hip -o build/k_search_fast.o 2> /dev/null
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/librtdm_hip.so build/*.o
+    K=$((K + 1)); F=$(echo "$V" | tr ',' ' ')
+    make -s variant NAME=fast$K VSRC=k_search_fast VFLAGS="$F" 2> /dev/null || { echo "build failed: $V"; continue; }
+    export RTDM_LIB_VARIANT=fast$K RTDM_RING=0
     python - "$V" <<'PY'
 import importlib, os, sys
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -29,3 +31,4 @@ for (D, w) in ((128, 11), (192, 13), (256, 15)):
     m.close()
 PY
 done
+rm -rf $R/rt-depth-map_amd/build_fast* $R/rt-depth-map_amd/lib/variants/librtdm_hip_fast*.so

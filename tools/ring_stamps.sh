@@ -1,10 +1,9 @@
 #!/bin/bash
-# Diagnostic build of k_search_ring with s_memtime stamps (run on the GPU box): prints the share of each segment of a row pair.
+# Diagnostic build of k_search_ring with s_memtime stamps (run on the GPU box), as a VARIANT library (never the shipped one):
+# prints the share of each segment of a row group.  Extra hipcc flags may follow.
 R=$GRAFT_REPO_ROOT
-cd $R/rt-depth-map_amd
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-result -DRING_STAMPS "$@" -c csrc/k_search_ring.hip -o build/k_search_ring.o 2> /dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o lib/librtdm_hip.so build/*.o
-cd $R && python - <<'PY'
+cd $R/rt-depth-map_amd && make -s variant NAME=stamps VSRC=k_search_ring VFLAGS="-DRING_STAMPS $*" 2> /dev/null || exit 1
+cd $R && RTDM_LIB_VARIANT=stamps python - <<'PY'
 import ctypes, importlib, torch
 pkg = importlib.import_module("rt-depth-map_amd")
 lib = pkg.binding.lib()
@@ -21,6 +20,7 @@ lib.rtdm_debug_ring_stamps(out, 1)
 m.compute_device(dL, dR, dD, st); torch.cuda.synchronize()
 lib.rtdm_debug_ring_stamps(out, 0)
 v = list(out); tot = sum(v)
-names = ["0 before pair", "1 LDS reads row A", "2 step A (SAD+commit)", "3 LDS reads row B", "4 step B (SAD+commit)", "5 swaps", "6 selection+stores", "7"]
-for n, x in zip(names, v): print("%-26s %14d  %5.1f %%" % (n, x, 100.0 * x / tot))
+names = ["0 before group", "1 LDS reads of the rows", "2 row steps (SAD+commit)", "3", "4", "5 selection", "6 stores", "7"]
+for n, x in zip(names, v): print("%-26s %14d  %5.1f %%" % (n, x, 100.0 * x / max(1, tot)))
 PY
+rm -rf $R/rt-depth-map_amd/build_stamps $R/rt-depth-map_amd/lib/variants/librtdm_hip_stamps.so

@@ -39,7 +39,8 @@ print("checked", count, "mismatches", bad, variants, flush=True)
 # ---- a strip, the side-stream border kernel, the autotuned strip count on the second and third call)
 RING = [(64, 9), (64, 7), (64, 5), (32, 7), (32, 9), (32, 11), (32, 13), (48, 7), (48, 9), (16, 5), (16, 7), (16, 9),
         (128, 7), (128, 9), (128, 11), (64, 9), (64, 7), (128, 11), (96, 9), (96, 13), (48, 13), (64, 13), (128, 13), (96, 11),
-        (64, 15), (128, 15), (32, 15), (48, 5), (32, 5), (16, 13), (16, 11), (48, 11), (64, 11), (96, 7)]
+        (64, 15), (128, 15), (32, 15), (48, 5), (32, 5), (16, 13), (16, 11), (48, 11), (64, 11), (96, 7),
+        (192, 13), (192, 9), (192, 11), (192, 15), (256, 15), (256, 9), (256, 11), (256, 13), (192, 13), (64, 9)]
 st = torch.cuda.current_stream().cuda_stream
 for seed in range(first, first + max(1, count // 10)):
     if (seed - first) % 100 == 0: print("ring case", seed - first, "mismatches so far", bad, flush=True)
