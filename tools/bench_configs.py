@@ -18,9 +18,11 @@ CONFIGS = [
     ("headline + ROI1 = 400x300 box (estimator.cpp:54)", 1280, 720, 64, 9, 64, (440, 210, 400, 300)),
     ("config3 1280x720 d=128 11x11", 1280, 720, 128, 11, 32, None),
     ("reference default 1280x720 d=192 13x13", 1280, 720, 192, 13, 32, None),
-    # the reference's own parameter set (main.cpp:134: blockSize 13; nd = 192 scaled by the frame width) at its smaller sizes
-    ("reference parameters at 640x480: d=96 13x13", 640, 480, 96, 13, 128, None),
-    ("reference parameters at 320x240: d=48 13x13", 320, 240, 48, 13, 256, None),
+    # the reference's own parameter set is d=192 13x13 at EVERY frame size (main.cpp:134-135, cmdline-parser.cpp:22; nd is NOT
+    # scaled with the width: cmdline-parser.h:85-89 divides by the parser's own width).  At 320 wide d=192 leaves 129 columns.
+    ("reference default at 640x480: d=192 13x13", 640, 480, 192, 13, 128, None),
+    ("reference default at 320x240: d=192 13x13", 320, 240, 192, 13, 256, None),
+    ("(96,13) ring form at 640x480 -- not a reference setting", 640, 480, 96, 13, 128, None),
 ]
 out = []
 cores = min(os.cpu_count() or 1, 64)
