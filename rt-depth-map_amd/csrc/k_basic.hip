@@ -377,7 +377,11 @@ struct alignas(16) Short8 { int16_t v[8]; };
 // 8 consecutive columns, so the row, its costs, the write-back and the head map each move as ONE 128-bit access
 // per thread (the scalar kernel spends its time issuing 2-byte accesses), and the run scan works on one
 // aggregate per thread instead of one LDS element per column.  Same results as the scalar kernel.
-template <bool SPK>
+// TWO (round 3): two rows per workgroup, one per HALF-wave -- lanes 0..31 of every wave take 32 chunks of row y, lanes 32..63
+// the same chunks of row y + 1.  A 1280-wide row is 160 chunks = five half-waves: five full waves per row pair instead of
+// three waves of which one is half empty per row (17 % of the lanes idle in a VALU-saturated kernel), and half the
+// barriers per row.  Scans stop at the half-wave boundary (no row_bcast:31 step), everything else is per thread.
+template <bool SPK, bool TWO>
 __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16_t* cost, BMGeom g, int maxDiff16,
                                                      int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                                                      int16_t* headmap, int spkDiff)
@@ -385,13 +389,18 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = g.W, INV = g.filtered;
     const int Wp = (W + 7) & ~7;                                      // LDS rows hold whole 8-column chunks
-    uint32_t* key = (uint32_t*)smem;                                  // Wp keys: cost << 16 | (d + 0x8000); key[W] stays "none", key[W+1] takes the votes nobody uses
-    int16_t* fin = (int16_t*)(key + Wp + 4);                          // Wp: the row after the check (SPK)
-    __shared__ int wsum[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int x0 = tid * 8;
-    const bool active = x0 < W;
-    const int f = blockIdx.z, y = g.vy0 + blockIdx.y;
+    const int half = TWO ? lane >> 5 : 0;                             // which of the workgroup's rows this lane works on
+    const int hl = TWO ? lane & 31 : lane;                            // lane inside the (half-)wave
+    const int chunk = TWO ? wv * 32 + hl : tid;
+    // per row: Wp keys: cost << 16 | (d + 0x8000); key[W] stays "none", key[W+1] takes the votes nobody uses; then the row after the check (SPK)
+    uint32_t* key = (uint32_t*)(smem + (size_t)half * ((size_t)Wp * 6 + 16));
+    int16_t* fin = (int16_t*)(key + Wp + 4);                          // Wp
+    __shared__ int wsum[2][8];
+    const int x0 = chunk * 8;
+    const int f = blockIdx.z, yu = g.vy0 + (TWO ? 2 * (int)blockIdx.y + half : (int)blockIdx.y);
+    const bool active = x0 < W && yu < g.vy1;                         // (an odd row count leaves the last workgroup's second half idle)
+    const int y = min(yu, g.vy1 - 1);
     const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
     int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
     const uint16_t* crow = cost + ((size_t)f * g.H + y) * g.Ws;
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
         const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
         ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
     }
-    if (tid == 0) { key[Wp] = ~0u; key[Wp + 1] = ~0u; }              // (W == Wp: the two extra slots lie behind the chunks)
+    if (chunk == 0) { key[Wp] = ~0u; key[Wp + 1] = ~0u; }            // (W == Wp: the two extra slots lie behind the chunks)
     __syncthreads();
     // Votes and look-ups are straight-line code for all eight columns (per-column branches cost more in exec-mask
     // bookkeeping than the work they skip).  The key of a vote carries the voter's DISPARITY, not its column: among the
@@ -490,20 +499,20 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
 #define RTDM_SCAN(ctrl, rmask) t = OpHead::f(t, __builtin_amdgcn_update_dpp(0, t, ctrl, rmask, 0xf, false))
     RTDM_SCAN(0x111, 0xf); RTDM_SCAN(0x112, 0xf); RTDM_SCAN(0x114, 0xf); RTDM_SCAN(0x118, 0xf);   // row_shr:1,2,4,8
     RTDM_SCAN(0x142, 0xa);                                                                          // row_bcast:15
-    RTDM_SCAN(0x143, 0xc);                                                                          // row_bcast:31
+    if constexpr (!TWO) { RTDM_SCAN(0x143, 0xc); }                                                  // row_bcast:31 (whole waves only)
 #undef RTDM_SCAN
-    if (lane == 63) wsum[wv] = t;
+    if (hl == (TWO ? 31 : 63)) wsum[half][wv] = t;
     __syncthreads();
     int run = __builtin_amdgcn_update_dpp(0, t, 0x138, 0xf, 0xf, false);                           // wave_shr:1
-    if (lane == 0) run = 0;
-    for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[q]);
+    if (hl == 0) run = 0;
+    for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[half][q]);
     if (!active) return;
     const int base = (f * g.H + y) * g.Ws;
     const int hin = (run & 0xffff) - 1, cin = run >> 16;             // head and run count carried in from the left
     // head record of the chunk, one dword instead of eight head columns: (head carried in from the left + 1) | starts << 16.
     // A pixel that is a disparity and not a run start belongs to the run of the nearest start to its left (in the chunk,
     // else the carried one); k_spk_merge_strip<RS, true> rebuilds the few heads it needs from that.
-    ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + tid] = (uint32_t)(hin + 1) | (hm << 16);
+    ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + chunk] = (uint32_t)(hin + 1) | (hm << 16);
     while (lm) {                                                      // one trip per run that ends in this chunk
         const int k = __builtin_ctz(lm);
         lm &= lm - 1;
@@ -536,10 +545,21 @@ bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
     const bool vec = k32 && (g.Ws & 7) == 0 && g.W <= 4096 && lr_rows() == 1 && disp.pitch_e >= (size_t)Wp &&   // that belong to the plane
                      (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2) | (size_t)cost | (size_t)headmap) & 15) == 0;
     if (vec) {
-        const dim3 vblock((unsigned)(((Wp >> 3) + 63) & ~63));
         const size_t lds = (size_t)Wp * 6 + 16;
-        if (label) hipLaunchKernelGGL(k_lrcheck_vec<true>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        else       hipLaunchKernelGGL(k_lrcheck_vec<false>, dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        static const int two_env = env_int("RTDM_LR_TWO_ROWS", 1);   // A/B: 0 = one row per workgroup (round 2)
+        const int chunks = Wp >> 3;
+        // two rows per workgroup where the half-wave form wastes fewer lanes than the whole-wave form and fits 512 threads
+        const int waves1 = (chunks + 63) / 64, waves2 = (chunks + 31) / 32;
+        const bool two = two_env && waves2 <= 8 && nrows >= 2 && waves2 < 2 * waves1;
+        if (two) {
+            const dim3 vblock((unsigned)(waves2 * 64)), vgrid(1, (nrows + 1) / 2, n);
+            if (label) hipLaunchKernelGGL((k_lrcheck_vec<true, true>), vgrid, vblock, 2 * lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+            else       hipLaunchKernelGGL((k_lrcheck_vec<false, true>), vgrid, vblock, 2 * lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+            return label != nullptr;
+        }
+        const dim3 vblock((unsigned)(waves1 * 64));
+        if (label) hipLaunchKernelGGL((k_lrcheck_vec<true, false>), dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL((k_lrcheck_vec<false, false>), dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
         return label != nullptr;
     } else if (label) {
         const int rr = lr_rows();

@@ -481,7 +481,8 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
             // grid a border workgroup takes a tile workgroup's slot for the length of its latency-bound walk
             // (search -2 %).  Single frames keep the fused launch (one kernel less).  RTDM_BORDER_ASYNC=0: always fused.
             static const bool async_border = [] { const char* e = getenv("RTDM_BORDER_ASYNC"); return !e || atoi(e) != 0; }();
-            const bool side = async_border && border_search_supported(g) && n >= 16;
+            static const int side_min = env_int("RTDM_BORDER_SIDE_MIN", 16);   // (A/B: smallest batch whose border columns get the side stream)
+            const bool side = async_border && border_search_supported(g) && n >= side_min;
             // (the 3.x clamp exists in the stand-alone border kernel only: the fused forms keep their register budget)
             const bool fuse = border_search_supported(g) && !separate && !side && !g.legacy;   // border workgroups inside the tile kernel's grid
             // (measured, if at all, before the side stream forks: nothing else runs beside the timed launches)
