@@ -116,7 +116,9 @@ struct RingCfg {
     static constexpr int RPG = ring_rpg(D, LPP);
     // selection without transposing the lanes' slices (GroupSelect / GroupSelectRec): always for four and more lanes per pixel;
     // with two lanes where it measured faster than transposing (tools/ring_split_ab.sh, profiles/r02_ring_split_select_ab.txt)
-    static constexpr bool SPLIT = LPP != 2 || D >= 48 || (D == 32 && WS == 9) || (RING_SPLIT_SELECT && RING_LDS_SELECT);
+    // (round 3 re-measured with GroupSelectRec: D = 32, w = 5 joins (+10 %); the other D = 16 / 32 forms stay within +-1-5 %
+    //  of transposing, profiles/r03_ring_split_select_ab.txt)
+    static constexpr bool SPLIT = LPP != 2 || D >= 48 || (D == 32 && (WS == 9 || WS == 5)) || (RING_SPLIT_SELECT && RING_LDS_SELECT);
     // the group minima live in the owner's record too and nothing crosses between the lanes (GroupSelectRec).  Not at D = 128
     // with eight rows per group: 64 records of 304 bytes would leave one workgroup per CU.
     static constexpr bool MINREC = SPLIT && RING_MINREC && !(D == 128 && RPG == 8) && !(D == 96 && !RING_MINREC96);
