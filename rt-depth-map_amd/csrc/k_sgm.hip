@@ -68,7 +68,19 @@ __device__ __forceinline__ int bt_cost(uint32_t a, uint32_t b)
     return min(c0, c1);
 }
 
-// pixel cost, u8: one thread per (x, four consecutive d); d fastest
+// pixel cost, u8: one thread per (x, four consecutive d); d fastest.  Round 3: two disparities per instruction in packed u16 --
+// max(0, u - v1, v0 - u) is max(u -sat v1, v0 -sat u) -- 11 VALU per (x, d) instead of ~30 (the kernel was VALU bound at 1.9 TB/s).
+typedef unsigned short sgm_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sgm_subs(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(sgm_us2, a), __builtin_bit_cast(sgm_us2, b))); }
+__device__ __forceinline__ uint32_t sgm_max2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(sgm_us2, a), __builtin_bit_cast(sgm_us2, b))); }
+__device__ __forceinline__ uint32_t sgm_min2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(sgm_us2, a), __builtin_bit_cast(sgm_us2, b))); }
+// bt_cost of one left pixel (u, u0, u1 replicated into both halves) against two right pixels (low / high half)
+__device__ __forceinline__ uint32_t bt_cost2(uint32_t U, uint32_t U0, uint32_t U1, uint32_t V, uint32_t V0, uint32_t V1)
+{ return sgm_min2(sgm_max2(sgm_subs(U, V1), sgm_subs(V0, U)), sgm_max2(sgm_subs(V, U1), sgm_subs(U0, V))); }
+
 __global__ __launch_bounds__(256) void k_sgm_pix(const uint2* bl, const uint2* br, uint8_t* pix, SGMGeom g)
 {
     const int dq = g.D >> 2;
@@ -79,14 +91,22 @@ __global__ __launch_bounds__(256) void k_sgm_pix(const uint2* bl, const uint2* b
     const int x = g.x0 + xi, xr = x - (d + g.minD);                     // element j pairs x with xr - j
     const size_t row = ((size_t)f * g.H + y) * g.W;
     const uint2 a = bl[row + x];
-    uint32_t out = 0;
+    uint2 b[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint2 b = br[row + xr - j];
-        const int c = bt_cost(a.x, b.x) + (bt_cost(a.y, b.y) >> 2);
-        out |= (uint32_t)c << (8 * j);
+    for (int j = 0; j < 4; ++j) b[j] = br[row + xr - j];
+    const auto rep = [](uint32_t w, int k) -> uint32_t { return ((w >> (8 * k)) & 0xffu) * 0x00010001u; };
+    const uint32_t Ug = rep(a.x, 0), Ug0 = rep(a.x, 1), Ug1 = rep(a.x, 2), Ur = rep(a.y, 0), Ur0 = rep(a.y, 1), Ur1 = rep(a.y, 2);
+    uint32_t c[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint2 lo = b[2 * p], hi = b[2 * p + 1];                   // low half: element 2p, high half: element 2p + 1
+        const uint32_t cg = bt_cost2(Ug, Ug0, Ug1, __builtin_amdgcn_perm(hi.x, lo.x, 0x0C040C00u), __builtin_amdgcn_perm(hi.x, lo.x, 0x0C050C01u),
+                                     __builtin_amdgcn_perm(hi.x, lo.x, 0x0C060C02u));
+        const uint32_t cr = bt_cost2(Ur, Ur0, Ur1, __builtin_amdgcn_perm(hi.y, lo.y, 0x0C040C00u), __builtin_amdgcn_perm(hi.y, lo.y, 0x0C050C01u),
+                                     __builtin_amdgcn_perm(hi.y, lo.y, 0x0C060C02u));
+        c[p] = cg + ((cr >> 2) & 0x003f003fu);                          // both <= 63 + 30: no carry between the halves
     }
-    *(uint32_t*)(pix + (((size_t)f * g.H + y) * g.W1 + xi) * g.D + d) = out;
+    *(uint32_t*)(pix + (((size_t)f * g.H + y) * g.W1 + xi) * g.D + d) = __builtin_amdgcn_perm(c[1], c[0], 0x06040200u);
 }
 
 // block cost: thread = (x, four consecutive d); walks down a strip of rows keeping the last 2R+1 horizontal sums in

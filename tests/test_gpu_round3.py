@@ -304,3 +304,50 @@ def test_reference_call_shape_d192_w13_views_with_roi1(pkg, oracle, synth, W, H,
     assert_same(Ov, oracle.bm_compute(np.ascontiguousarray(Lv), np.ascontiguousarray(Rv), numDisparities=192, blockSize=13, roi1=roi))
     guard = plane.copy(); guard[cy:cy + ch, cx:cx + cw] = 777
     assert (guard == 777).all()
+
+
+# ---- k_search_border2 (rows in the lanes) against k_search_border (disparities in the lanes) and the oracle ------------
+# The switch is read once per process, so each setting runs in a process of its own.  Shapes: rows fewer / more than one
+# wave's 64 - (w - 1), ROI1 (vy0 > r, searched columns cut), both minDisparity signs, every window class (NSP 2, 3, 4), a
+# frame too narrow for the anchored span (falls back), cap 63 (falls back: packed prefix sums), batches on the side stream.
+_BORDER_CASES = r'''
+import importlib, sys, zlib, numpy as np, torch
+sys.path.insert(0, %r)
+pkg = importlib.import_module("rt-depth-map_amd")
+from oracle import oracle as orc
+orc.build()
+cases = [(64, 9, 0, 300, 40, None, 31, 1), (64, 9, 0, 300, 131, None, 31, 1), (32, 7, 0, 233, 156, (49, 30, 150, 90), 31, 1),
+         (16, 5, 0, 90, 70, None, 31, 1), (128, 11, 0, 420, 100, None, 31, 1), (64, 15, 0, 260, 90, None, 15, 1),
+         (64, 13, -5, 300, 80, None, 31, 1), (32, 9, 4, 200, 75, None, 31, 1), (64, 9, 0, 80, 60, None, 31, 1),
+         (32, 9, 0, 250, 66, None, 63, 1), (192, 13, 0, 500, 120, None, 31, 1), (64, 9, 0, 640, 200, None, 31, 20),
+         (256, 15, 0, 560, 90, None, 15, 1), (48, 7, 0, 301, 57, (0, 0, 301, 40), 31, 1)]
+for (D, w, minD, W, H, roi, cap, n) in cases:
+    Ls, Rs = pkg.synth.make_stream(123 + D + w, n, W, H, D)
+    m = pkg.HIPMatcher(numOfDisparities=D, blockSize=w, minDisparity=minD, preFilterCap=cap, width=W, height=H, max_batch=n)
+    if roi: m.setROI1(roi)
+    if n == 1:
+        got = m.compute(Ls[0], Rs[0])[None]
+    else:
+        dL, dR = torch.from_numpy(Ls).cuda(), torch.from_numpy(Rs).cuda()
+        dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+        m.compute_device(dL, dR, dD, torch.cuda.current_stream().cuda_stream); torch.cuda.synchronize()
+        got = dD.cpu().numpy()
+    m.close()
+    for i in sorted({0, n - 1}):
+        want = orc.bm_compute(Ls[i], Rs[i], numDisparities=D, blockSize=w, minDisparity=minD, preFilterCap=cap, roi1=roi)
+        assert np.array_equal(got[i], want), ("oracle", D, w, minD, W, H, roi, cap, i, int((got[i] != want).sum()))
+    print("CRC", D, w, minD, W, H, zlib.crc32(got.tobytes()))
+print("ok")
+'''
+
+
+def test_border2_equals_border_and_the_oracle():
+    import subprocess, sys
+    outs = {}
+    for flag in ("1", "0"):
+        env = dict(os.environ, RTDM_BORDER2=flag)
+        p = subprocess.run([sys.executable, "-c", _BORDER_CASES % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=900, env=env)
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-3000:]
+        outs[flag] = [ln for ln in p.stdout.splitlines() if ln.startswith("CRC")]
+    assert outs["1"] == outs["0"] and len(outs["1"]) == 14
