@@ -90,6 +90,8 @@ struct RingGeom {
     unsigned nitems;     // workgroups over the whole batch
     unsigned chunk;      // ceil(nitems / 8): consecutive items one XCD works through (0: no remapping)
     uint32_t rdelta;     // the right prefiltered plane lies this many bytes behind the left one (direct loads)
+    int rebase;          // > 0: every `rebase` trips of the row loop the ring is rebased (P -= the oldest live prefix sum), so a
+                         // strip may be as long as the frame; 0: strips are short enough for 16-bit prefix sums (ring_rows_cap)
     unsigned nborder;    // border-column workgroups in FRONT of the tile workgroups (single frames and small batches, where a
     int bgx, bgy;        // second launch or a side stream costs more than it hides; rtdm_border.h); 0: none
 };
@@ -479,7 +481,24 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
 
     // One trip of the outer loop = whole rounds of the ring AND whole row groups (TRIP rows), unrolled: every row step has
     // its ring slot -- its registers -- fixed at compile time.
+    int trips_since_rebase = 0;
     for (int t0 = 0; t0 < nstepsg; t0 += C::TRIP) {
+        // Rebase (round 3): a trip starts on ring slot 0, whose content P(t-w-1) is dead; slot 1 holds the oldest prefix sum
+        // still needed, P(t-w).  Subtracting it from every live slot (per 16-bit half, no borrow: prefix sums only grow)
+        // leaves all window sums unchanged and keeps the halves below 2^16 for another rg.rebase trips -- strips no longer have
+        // to be short, and a long strip pays the w-1 window-filling rows once instead of once per ~100 rows.
+        if (rg.rebase && ++trips_since_rebase > rg.rebase) {
+            trips_since_rebase = 1;
+#pragma unroll
+            for (int i = 0; i < NGL; ++i) {
+                const uint32_t blo = (uint32_t)st.P[1][i], bhi = (uint32_t)(st.P[1][i] >> 32);
+#pragma unroll
+                for (int k = 1; k < W1; ++k) {
+                    const uint32_t lo = (uint32_t)st.P[k][i] - blo, hi = (uint32_t)(st.P[k][i] >> 32) - bhi;
+                    st.P[k][i] = (uint64_t)lo | ((uint64_t)hi << 32);
+                }
+            }
+        }
         ring_for_groups(std::make_integer_sequence<int, C::TRIP / RPG>{}, [&](auto Uc) -> bool {
             constexpr int U = RPG * decltype(Uc)::value;
             const int t = t0 + U;
@@ -578,6 +597,20 @@ static bool ring_range(const BMGeom& g, int* x0, int* nx)
 // rows a strip may have so that no prefix sum leaves 16 bits: a row adds at most w * 2 cap per disparity, and a strip of
 // rs output rows walks rs + w - 1 rows plus up to seven padded rows (groups of eight)
 static int ring_rows_cap(const BMGeom& g) { return 65535 / (g.w * 2 * g.cap) - g.w - 6; }
+static int ring_lpp(const BMGeom& g);
+// trips of the row loop between two rebases of the ring (0: one trip is longer than the cap -- no rebasing, short strips)
+static int ring_rebase_trips(const BMGeom& g)
+{
+    static const int enabled = env_int("RTDM_RING_REBASE", 1);        // A/B switch: 0 = short strips (round 2)
+    const int lpp = ring_lpp(g);
+    if (!enabled || !lpp) return 0;
+    const int W1 = g.w + 1, rpg = ring_rpg(g.D, lpp);
+    const int trip = (W1 % rpg == 0) ? W1 : (2 * W1 % rpg == 0) ? 2 * W1 : 4 * W1;   // RingCfg::TRIP
+    return ring_rows_cap(g) / trip;
+}
+// strips a frame must at least be cut into
+static int ring_min_strips(const BMGeom& g, int nrows)
+{ return ring_rebase_trips(g) > 0 ? 1 : max(1, (nrows + ring_rows_cap(g) - 1) / ring_rows_cap(g)); }
 
 // Instantiations: (D, blockSize, lanes per pixel).  Two lanes per pixel: every (D, blockSize) whose ring (blockSize+1) * D/4
 // registers per lane leaves room for two waves per SIMD.  Four lanes per pixel: the D = 64 ones, whose two-lane ring holds
@@ -638,7 +671,7 @@ int ring_strips_model(const BMGeom& g, int n)
     if (!ring_range(g, &x0, &nx) || !ring_lpp(g)) return 1;
     const int tile = ring_tile(g), tiles = (nx + tile - 1) / tile, nrows = g.vy1 - g.vy0;
     const int slots = 256 * ring_wgs_per_cu(g);             // workgroups in flight on the chip
-    const int smin = max(1, (nrows + ring_rows_cap(g) - 1) / ring_rows_cap(g)), smax = max(smin, (nrows + 15) / 16);
+    const int smin = ring_min_strips(g, nrows), smax = max(smin, (nrows + 15) / 16);
     // a strip pays w-1 filling rows at about half the price of an output row
     const float fill = 0.5f * (float)(g.w - 1);
     int s = (int)(sqrtf((float)nrows * (float)slots / (fill * (float)tiles * (float)n)) + 0.5f);
@@ -671,8 +704,8 @@ static bool ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
     const int nrows = g.vy1 - g.vy0;
     const int tiles = (rg.nx + C::TILE - 1) / C::TILE;
     int strips = strips_hint > 0 ? strips_hint : ring_strips_model(g, n);
-    const int cap = ring_rows_cap(g);
-    strips = max(strips, (nrows + cap - 1) / cap);
+    strips = max(strips, ring_min_strips(g, nrows));
+    rg.rebase = ring_rebase_trips(g);                 // (= ring_rows_cap / C::TRIP)
     strips = max(1, min(strips, nrows));
     rg.rs = (nrows + strips - 1) / strips;
     strips = (nrows + rg.rs - 1) / rg.rs;
