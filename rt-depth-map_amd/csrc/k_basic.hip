@@ -509,20 +509,22 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     if (!active) return;
     const int base = (f * g.H + y) * g.Ws;
     const int hin = (run & 0xffff) - 1, cin = run >> 16;             // head and run count carried in from the left
-    // head record of the chunk, one dword instead of eight head columns: (head carried in from the left + 1) | starts << 16.
-    // A pixel that is a disparity and not a run start belongs to the run of the nearest start to its left (in the chunk,
-    // else the carried one); k_spk_merge_strip<RS, true> rebuilds the few heads it needs from that.
-    ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + chunk] = (uint32_t)(hin + 1) | (hm << 16);
+    // head record of the chunk, one dword instead of eight head columns: (runs that start left of the chunk) | starts << 16.
+    // The union-find node of a run is its INDEX in the row (dense: a row's labels, sizes and run list are a few contiguous
+    // lines instead of one touched sector per run head -- the count / apply passes and this kernel's own stores used to
+    // scatter over the whole plane): the pixel at bit k belongs to run cin + popcount(starts at or left of k), 1-based;
+    // k_spk_merge_strip<RS, true> rebuilds the few nodes it needs from that.
+    ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + chunk] = (uint32_t)cin | (hm << 16);
     while (lm) {                                                      // one trip per run that ends in this chunk
         const int k = __builtin_ctz(lm);
         lm &= lm - 1;
         const unsigned hb = hm & ((2u << k) - 1u);                    // heads at or left of the end
         const int h = hb ? x0 + (31 - __builtin_clz(hb)) : hin;
-        const int idx = cin + __builtin_popcount(hb);                 // 1-based index of this run in the row
+        const int node = base + cin + __builtin_popcount(hb) - 1;     // (1-based index of this run in the row) - 1
         const int len = x0 + k - h + 1;
-        label[base + h] = base + h;
-        size[base + h] = len;
-        runs[base + idx - 1] = (uint32_t)h | ((uint32_t)len << 16);
+        label[node] = node;
+        size[node] = len;
+        runs[node] = (uint32_t)h | ((uint32_t)len << 16);
     }
     if (x0 + 8 >= W) rowcnt[f * g.H + y] = cin + __builtin_popcount(hm);
 }
@@ -744,9 +746,10 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
             while (cand) {
                 const int k = __builtin_ctz(cand);
                 cand &= cand - 1;
+                // nodes = run indices (k_lrcheck_vec): runs that start left of the chunk + starts at or left of the pixel, - 1
                 const unsigned ma = startA & ((2u << k) - 1u), mb = startB & ((2u << k) - 1u);
-                const int ha = ma ? x0 + (31 - __builtin_clz(ma)) : (int)(ca & 0xffffu) - 1;
-                const int hb = mb ? x0 + (31 - __builtin_clz(mb)) : (int)(cb & 0xffffu) - 1;
+                const int ha = (int)(ca & 0xffffu) + __builtin_popcount(ma) - 1;
+                const int hb = (int)(cb & 0xffffu) + __builtin_popcount(mb) - 1;
                 const int slot = atomicAdd(&qn, 1);
                 if (slot < QCAP) queue[slot] = make_int2(base + ha, base + Ws + hb);
                 else uf_union(label, base + ha, base + Ws + hb);
@@ -797,6 +800,8 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     }
 }
 
+// DENSE: the node of a run is base + its index in the row (k_lrcheck_vec), else base + the x of its head (spk_row_init).
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size, const uint32_t* runs,
                                                    const int32_t* rowcnt, int Ws, int nrows, int maxSize)
 {
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size
     const int cnt = rowcnt[row], base = row * Ws;
     for (int i = threadIdx.x & 15; i < cnt; i += 16) {
         const uint32_t rn = runs[base + i];
-        const int idx = base + (int)(rn & 0xffffu), len = (int)(rn >> 16);
+        const int idx = base + (DENSE ? i : (int)(rn & 0xffffu)), len = (int)(rn >> 16);
         const int root = uf_find(label, idx);
         if (root == idx) continue;
         st_relaxed(&label[idx], root);             // roots are final in this launch
@@ -813,6 +818,7 @@ __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size
     }
 }
 
+template <bool DENSE>
 __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t* label, const int32_t* size,
                                                    const uint32_t* runs, const int32_t* rowcnt, int Ws, int H, int nrows,
                                                    int newVal, int maxSize)
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(256) void k_spk_apply(Plane16W disp, const int32_t*
         if (len > maxSize) continue;               // a run longer than the limit is in a large component by itself
         // after k_spk_count a head is at most a couple of hops from its root (a late path-halving
         // store of another thread may have left an ancestor instead of the root), so chase it
-        int root = base + x;
+        int root = base + (DENSE ? i : x);
         for (int p = label[root]; p != root; p = label[root]) root = p;
         if (size[root] <= maxSize)
             for (int k = 0; k < len; ++k) drow[x + k] = (int16_t)newVal;
@@ -873,8 +879,13 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
     }
     const int nrows = n * H;
-    hipLaunchKernelGGL(k_spk_count, dim3((nrows + 15) / 16), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
-    hipLaunchKernelGGL(k_spk_apply, dim3((nrows + 15) / 16), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
+    if (compact_heads) {                          // k_lrcheck_vec: nodes are run indices
+        hipLaunchKernelGGL(k_spk_count<true>, dim3((nrows + 15) / 16), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
+        hipLaunchKernelGGL(k_spk_apply<true>, dim3((nrows + 15) / 16), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
+    } else {
+        hipLaunchKernelGGL(k_spk_count<false>, dim3((nrows + 15) / 16), block, 0, stream, label, size, runs, rowcnt, Ws, nrows, maxSize);
+        hipLaunchKernelGGL(k_spk_apply<false>, dim3((nrows + 15) / 16), block, 0, stream, disp, label, size, runs, rowcnt, Ws, H, nrows, newVal, maxSize);
+    }
 }
 
 }  // namespace rtdm
