@@ -373,6 +373,20 @@ __global__ __launch_bounds__(256) void k_lrcheck(Plane16W disp, const CT* cost, 
 
 struct alignas(16) Short8 { int16_t v[8]; };
 
+// A contact between two runs of which at least one is longer than maxSize needs no union: only "component size <= maxSize"
+// is ever asked, the long run's component is large whatever else it touches, and so is the other run's -- which is MARKED
+// instead (its size becomes maxSize + 1: no find, no hook; k_spk_count adds a non-root's size to its root, so the mark
+// reaches the root of whatever small runs are united with it, and a later contact of a marked run marks its neighbour in
+// turn).  Exact: marks only ever appear in components that contain a long run, and every short run of such a component is
+// reached from the long run through contacts that either united the two trees or marked the far end.  size[] holds the run
+// lengths (and marks) until k_spk_count runs.  Returns true if the contact is dealt with.
+__device__ __forceinline__ bool spk_large_contact(int32_t* size, int a, int b, int maxSize)
+{
+    const bool la = ld_relaxed(&size[a]) > maxSize, lb = ld_relaxed(&size[b]) > maxSize;
+    if (la != lb) atomicMax(&size[la ? b : a], maxSize + 1);
+    return la || lb;
+}
+
 // Vector form of k_lrcheck<SPK, uint16_t, uint32_t, 1> for 16-byte-aligned rows with W % 8 == 0: one thread owns
 // 8 consecutive columns, so the row, its costs, the write-back and the head map each move as ONE 128-bit access
 // per thread (the scalar kernel spends its time issuing 2-byte accesses), and the run scan works on one
@@ -381,11 +395,22 @@ struct alignas(16) Short8 { int16_t v[8]; };
 // the same chunks of row y + 1.  A 1280-wide row is 160 chunks = five half-waves: five full waves per row pair instead of
 // three waves of which one is half empty per row (17 % of the lanes idle in a VALU-saturated kernel), and half the
 // barriers per row.  Scans stop at the half-wave boundary (no row_bcast:31 step), everything else is per thread.
-template <bool SPK, bool TWO>
+// NIT > 1 (SPK and TWO only): the workgroup walks NIT row pairs, 2 NIT consecutive rows, and finds the speckle filter's
+// vertical contacts on the way -- while a row and the row above it are both in LDS -- for every pair of rows inside the block:
+// the chunk's head record gets 8 more bits, `cand`: bit k = "the pixel at column x0 + k touches the pixel above it, and that
+// contact is not the continuation of the contact to its left" (one union per contact segment).  k_spk_merge_rec then reads
+// the 4-byte records only (0.5 bytes per pixel; k_spk_merge_strip read the disparity plane again and was HBM bound at
+// 0.75 ms per 1024 720p pairs) and k_spk_merge_strip<1> is left with the one pair in 2 NIT that crosses two blocks.
+// A thread compares ITS row (registers) with the row above: the other half-wave's current row (upper half) or the upper
+// half's row of the previous trip (lower half) -- one 16-byte LDS read; the partner lane's run starts come by v_permlane32_swap.
+template <bool SPK, bool TWO, int NIT>
 __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16_t* cost, BMGeom g, int maxDiff16,
                                                      int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
                                                      int16_t* headmap, int spkDiff)
 {
+    static_assert(NIT == 1 || (SPK && TWO), "merging walks row pairs");
+    constexpr bool MERGE = NIT > 1;
+    constexpr int NB = MERGE ? 2 : 1;                                 // buffers of the final rows
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int W = g.W, INV = g.filtered;
     const int Wp = (W + 7) & ~7;                                      // LDS rows hold whole 8-column chunks
@@ -393,146 +418,229 @@ __global__ __launch_bounds__(512) void k_lrcheck_vec(Plane16W disp, const uint16
     const int half = TWO ? lane >> 5 : 0;                             // which of the workgroup's rows this lane works on
     const int hl = TWO ? lane & 31 : lane;                            // lane inside the (half-)wave
     const int chunk = TWO ? wv * 32 + hl : tid;
-    // per row: Wp keys: cost << 16 | (d + 0x8000); key[W] stays "none", key[W+1] takes the votes nobody uses; then the row after the check (SPK)
-    uint32_t* key = (uint32_t*)(smem + (size_t)half * ((size_t)Wp * 6 + 16));
-    int16_t* fin = (int16_t*)(key + Wp + 4);                          // Wp
+    // per row: Wp keys: cost << 16 | (d + 0x8000); key[W] stays "none", key[W+1] takes the votes nobody uses; then the row
+    // after the check (SPK; NB of them)
+    const size_t per_half = (size_t)Wp * 4 + 16 + (size_t)NB * Wp * 2;
+    uint32_t* key = (uint32_t*)(smem + (size_t)half * per_half);
+    int16_t* fin0 = (int16_t*)(key + Wp + 4);                         // NB x Wp
+    // the other half's rows: the row above an upper-half row is the lower half's current row, the row above a lower-half
+    // row is the upper half's row of the previous trip
+    const int16_t* ofin0 = (const int16_t*)((uint32_t*)(smem + (size_t)(half ^ 1) * per_half) + Wp + 4);
     __shared__ int wsum[2][8];
     const int x0 = chunk * 8;
-    const int f = blockIdx.z, yu = g.vy0 + (TWO ? 2 * (int)blockIdx.y + half : (int)blockIdx.y);
-    const bool active = x0 < W && yu < g.vy1;                         // (an odd row count leaves the last workgroup's second half idle)
-    const int y = min(yu, g.vy1 - 1);
+    const int f = blockIdx.z;
     const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
-    int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-    const uint16_t* crow = cost + ((size_t)f * g.H + y) * g.Ws;
-    Short8 d8, c8;
     // per-thread column masks (bit k = column x0 + k): inside the image / allowed to vote / inside the valid rectangle
     const auto span = [&](int lo, int hi) -> unsigned {
         const int a = min(max(lo - x0, 0), 8), b = min(max(hi - x0, 0), 8);
         return b > a ? ((1u << b) - 1u) & ~((1u << a) - 1u) : 0u;
     };
     const unsigned inimg = span(0, W), votem = span(minX1, maxX1), keepm = span(g.vx0, g.vx1);
-    unsigned im = 0;                                                  // bit k: d8.v[k] is a disparity (not INV)
-    if (active) {
-        d8 = *(const Short8*)(row + x0);
-        c8 = *(const Short8*)(crow + x0);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            if (!((inimg >> k) & 1)) d8.v[k] = (int16_t)INV;          // ragged last chunk: padding columns do not exist
-            im |= (unsigned)(d8.v[k] != INV) << k;
-        }
-        const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
-        ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
-    }
     if (chunk == 0) { key[Wp] = ~0u; key[Wp + 1] = ~0u; }            // (W == Wp: the two extra slots lie behind the chunks)
-    __syncthreads();
-    // Votes and look-ups are straight-line code for all eight columns (per-column branches cost more in exec-mask
-    // bookkeeping than the work they skip).  The key of a vote carries the voter's DISPARITY, not its column: among the
-    // voters of one right column a smaller x means a smaller disparity (x - x2 is its rounded integer part), so the
-    // minimum still prefers the lower cost and then the first voter, and a look-up has the winner's disparity without a
-    // second read.  A column that may not vote, or whose target lies outside the row, votes into key[W+1]; a look-up
-    // outside the row reads key[W], which nobody writes: "no vote".
-    if (active) {
-        const unsigned vm = im & votem;
+    uint32_t prev_mine = 0;                                           // MERGE: run starts | disparity mask << 8 of the previous trip's row
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+        const int ypair = TWO ? 2 * ((int)blockIdx.y * NIT + it) : (int)blockIdx.y;   // first row of this trip, from vy0
+        if (MERGE && g.vy0 + ypair >= g.vy1) break;                   // (uniform) the frame's rows end inside this block
+        const int yu = g.vy0 + ypair + half;
+        const bool active = x0 < W && yu < g.vy1;                     // (an odd row count leaves the last trip's second half idle)
+        const int y = min(yu, g.vy1 - 1);
+        const int cur = MERGE ? it & 1 : 0;
+        int16_t* fin = fin0 + (size_t)cur * Wp;
+        int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+        const uint16_t* crow = cost + ((size_t)f * g.H + y) * g.Ws;
+        Short8 d8, c8;
+        unsigned im = 0;                                              // bit k: d8.v[k] is a disparity (not INV)
+        if (active) {
+            d8 = *(const Short8*)(row + x0);
+            c8 = *(const Short8*)(crow + x0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int x = x0 + k, d = d8.v[k];
-            const int x2 = x - ((d + 8) >> 4);
-            const bool ok = ((vm >> k) & 1) && (unsigned)x2 < (unsigned)W;
-            atomicMin(&key[ok ? x2 : W + 1], ((uint32_t)(uint16_t)c8.v[k] << 16) | ((uint32_t)(d + 0x8000) & 0xffffu));
+            for (int k = 0; k < 8; ++k) {
+                if (!((inimg >> k) & 1)) d8.v[k] = (int16_t)INV;      // ragged last chunk: padding columns do not exist
+                im |= (unsigned)(d8.v[k] != INV) << k;
+            }
+            const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
+            ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
         }
-    }
-    __syncthreads();
-    if (active) {
-        const unsigned chk = im & votem & keepm;                      // columns whose two matches are looked up
-        unsigned kill = im & ~keepm;                                  // outside the valid rectangle: always dropped
-        // |d2 - d| > M  <=>  (unsigned)(d2 - d + M) > 2 M; unchecked columns are masked once, at the end
-        const unsigned M2 = 2u * (unsigned)maxDiff16;
-        const int dofs = maxDiff16 - 0x8000;
-        unsigned bad0m = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int x = x0 + k, d = d8.v[k];
-            const uint32_t q = key[min((unsigned)(x - (d >> 4)), (unsigned)W)];
-            bad0m |= ((unsigned)(q != ~0u) & (unsigned)((unsigned)((int)(q & 0xffffu) - d + dofs) > M2)) << k;
-        }
-        bad0m &= chk;
-        // a pixel dies only if BOTH matches disagree: the second look-ups are needed only where the first ones did
-        // (consistent regions: by none of the wave's lanes)
-        if (__builtin_amdgcn_ballot_w64(bad0m != 0) != 0) {
-            unsigned bad1m = 0;
+        __syncthreads();
+        // Votes and look-ups are straight-line code for all eight columns (per-column branches cost more in exec-mask
+        // bookkeeping than the work they skip).  The key of a vote carries the voter's DISPARITY, not its column: among the
+        // voters of one right column a smaller x means a smaller disparity (x - x2 is its rounded integer part), so the
+        // minimum still prefers the lower cost and then the first voter, and a look-up has the winner's disparity without a
+        // second read.  A column that may not vote, or whose target lies outside the row, votes into key[W+1]; a look-up
+        // outside the row reads key[W], which nobody writes: "no vote".
+        if (active) {
+            const unsigned vm = im & votem;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int x = x0 + k, d = d8.v[k];
-                const uint32_t q = key[min((unsigned)(x - ((d + 15) >> 4)), (unsigned)W)];
-                bad1m |= ((unsigned)(q != ~0u) & (unsigned)((unsigned)((int)(q & 0xffffu) - d + dofs) > M2)) << k;
+                const int x2 = x - ((d + 8) >> 4);
+                const bool ok = ((vm >> k) & 1) && (unsigned)x2 < (unsigned)W;
+                atomicMin(&key[ok ? x2 : W + 1], ((uint32_t)(uint16_t)c8.v[k] << 16) | ((uint32_t)(d + 0x8000) & 0xffffu));
             }
-            kill |= bad0m & bad1m;
         }
-        if (kill) {
+        __syncthreads();
+        if (active) {
+            const unsigned chk = im & votem & keepm;                  // columns whose two matches are looked up
+            unsigned kill = im & ~keepm;                              // outside the valid rectangle: always dropped
+            // |d2 - d| > M  <=>  (unsigned)(d2 - d + M) > 2 M; unchecked columns are masked once, at the end
+            const unsigned M2 = 2u * (unsigned)maxDiff16;
+            const int dofs = maxDiff16 - 0x8000;
+            unsigned bad0m = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) if ((kill >> k) & 1) d8.v[k] = (int16_t)INV;
-            *(Short8*)(row + x0) = d8;
-            im &= ~kill;
+            for (int k = 0; k < 8; ++k) {
+                const int x = x0 + k, d = d8.v[k];
+                const uint32_t q = key[min((unsigned)(x - (d >> 4)), (unsigned)W)];
+                bad0m |= ((unsigned)(q != ~0u) & (unsigned)((unsigned)((int)(q & 0xffffu) - d + dofs) > M2)) << k;
+            }
+            bad0m &= chk;
+            // a pixel dies only if BOTH matches disagree: the second look-ups are needed only where the first ones did
+            // (consistent regions: by none of the wave's lanes)
+            if (__builtin_amdgcn_ballot_w64(bad0m != 0) != 0) {
+                unsigned bad1m = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int x = x0 + k, d = d8.v[k];
+                    const uint32_t q = key[min((unsigned)(x - ((d + 15) >> 4)), (unsigned)W)];
+                    bad1m |= ((unsigned)(q != ~0u) & (unsigned)((unsigned)((int)(q & 0xffffu) - d + dofs) > M2)) << k;
+                }
+                kill |= bad0m & bad1m;
+            }
+            if (kill) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if ((kill >> k) & 1) d8.v[k] = (int16_t)INV;
+                *(Short8*)(row + x0) = d8;
+                im &= ~kill;
+            }
+            if (SPK) *(Short8*)(fin + x0) = d8;
         }
-        if (SPK) *(Short8*)(fin + x0) = d8;
-    }
-    if (!SPK) return;
-    __syncthreads();
-    // ---- speckle init of the finished row (what spk_row_init does, on per-thread aggregates) ----
-    int left = INV, right = INV;
-    if (active) { if (x0 > 0) left = fin[x0 - 1]; if (x0 + 8 < W) right = fin[x0 + 8]; }
-    // cb bit k (k = 0..8): columns x0+k-1 and x0+k are connected (both disparities, close enough)
-    unsigned cb = 0;
-    if (active) {
-        cb |= (unsigned)conn(left, d8.v[0], INV, spkDiff);
+        if (!SPK) return;                                             // (NIT == 1)
+        __syncthreads();
+        // ---- speckle init of the finished row (what spk_row_init does, on per-thread aggregates) ----
+        int left = INV, right = INV;
+        if (active) { if (x0 > 0) left = fin[x0 - 1]; if (x0 + 8 < W) right = fin[x0 + 8]; }
+        // cb bit k (k = 0..8): columns x0+k-1 and x0+k are connected (both disparities, close enough)
+        unsigned cb = 0;
+        if (active) {
+            cb |= (unsigned)conn(left, d8.v[0], INV, spkDiff);
 #pragma unroll
-        for (int k = 1; k < 8; ++k) cb |= (unsigned)(abs((int)d8.v[k] - (int)d8.v[k - 1]) <= spkDiff) << k;
-        cb &= (im & (im << 1)) | 1u;                                  // bits 1..7 need both columns to be disparities
-        cb |= (unsigned)conn(d8.v[7], right, INV, spkDiff) << 8;
-    }
-    const unsigned hm = im & ~cb & 0xffu;                             // run heads
-    unsigned lm = im & ~(cb >> 1) & 0xffu;                            // run ends
-    const int agg = hm ? ((__builtin_popcount(hm) << 16) | (x0 + (31 - __builtin_clz(hm)) + 1)) : 0;
-    // inclusive wave scan with DPP row shifts / row broadcasts (a __shfl_up chain is six dependent LDS-crossbar round
-    // trips); lanes without a source get the identity 0
-    int t = agg;
+            for (int k = 1; k < 8; ++k) cb |= (unsigned)(abs((int)d8.v[k] - (int)d8.v[k - 1]) <= spkDiff) << k;
+            cb &= (im & (im << 1)) | 1u;                              // bits 1..7 need both columns to be disparities
+            cb |= (unsigned)conn(d8.v[7], right, INV, spkDiff) << 8;
+        }
+        const unsigned hm = im & ~cb & 0xffu;                         // run heads
+        unsigned lm = im & ~(cb >> 1) & 0xffu;                        // run ends
+        // ---- contacts between this thread's row (B, registers) and the row above it (A, LDS) ----
+        unsigned cand = 0;
+        if constexpr (MERGE) {
+            const uint32_t mine = active ? (hm | (im << 8)) : 0u;
+            const uint32_t give = half ? prev_mine : mine;            // what the partner lane (same chunk, other half) wants to see
+            const auto sw = __builtin_amdgcn_permlane32_swap(give, give, false, false);   // {lower lanes' value, upper lanes' value}, in every lane
+            const uint32_t above = half ? sw[0] : sw[1];              // upper half: the lower half's row; lower half: the upper half's previous row
+            prev_mine = mine;
+            if (active && (half == 1 || it > 0)) {
+                const int16_t* afin = ofin0 + (size_t)(half == 1 ? cur : cur ^ 1) * Wp;
+                const Short8 a8 = *(const Short8*)(afin + x0);
+                const unsigned startA = above & 0xffu, ima = (above >> 8) & 0xffu;
+                unsigned cm = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) cm |= (unsigned)(abs((int)a8.v[k] - (int)d8.v[k]) <= spkDiff) << k;
+                cm &= ima & im;
+                // a contact repeats the union of the contact to its left iff neither pixel of the pair starts a run
+                const unsigned leftc = (cm & 1u) && x0 > 0 ? (unsigned)conn(afin[x0 - 1], left, INV, spkDiff) : 0u;
+                cand = cm & ~(((cm << 1) | leftc) & ~startA & ~hm);
+            }
+        }
+        const int agg = hm ? ((__builtin_popcount(hm) << 16) | (x0 + (31 - __builtin_clz(hm)) + 1)) : 0;
+        // inclusive wave scan with DPP row shifts / row broadcasts (a __shfl_up chain is six dependent LDS-crossbar round
+        // trips); lanes without a source get the identity 0
+        int t = agg;
 #define RTDM_SCAN(ctrl, rmask) t = OpHead::f(t, __builtin_amdgcn_update_dpp(0, t, ctrl, rmask, 0xf, false))
-    RTDM_SCAN(0x111, 0xf); RTDM_SCAN(0x112, 0xf); RTDM_SCAN(0x114, 0xf); RTDM_SCAN(0x118, 0xf);   // row_shr:1,2,4,8
-    RTDM_SCAN(0x142, 0xa);                                                                          // row_bcast:15
-    if constexpr (!TWO) { RTDM_SCAN(0x143, 0xc); }                                                  // row_bcast:31 (whole waves only)
+        RTDM_SCAN(0x111, 0xf); RTDM_SCAN(0x112, 0xf); RTDM_SCAN(0x114, 0xf); RTDM_SCAN(0x118, 0xf);   // row_shr:1,2,4,8
+        RTDM_SCAN(0x142, 0xa);                                                                          // row_bcast:15
+        if constexpr (!TWO) { RTDM_SCAN(0x143, 0xc); }                                                  // row_bcast:31 (whole waves only)
 #undef RTDM_SCAN
-    if (hl == (TWO ? 31 : 63)) wsum[half][wv] = t;
-    __syncthreads();
-    int run = __builtin_amdgcn_update_dpp(0, t, 0x138, 0xf, 0xf, false);                           // wave_shr:1
-    if (hl == 0) run = 0;
-    for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[half][q]);
-    if (!active) return;
-    const int base = (f * g.H + y) * g.Ws;
-    const int hin = (run & 0xffff) - 1, cin = run >> 16;             // head and run count carried in from the left
-    // head record of the chunk, one dword instead of eight head columns: (runs that start left of the chunk) | starts << 16.
-    // The union-find node of a run is its INDEX in the row (dense: a row's labels, sizes and run list are a few contiguous
-    // lines instead of one touched sector per run head -- the count / apply passes and this kernel's own stores used to
-    // scatter over the whole plane): the pixel at bit k belongs to run cin + popcount(starts at or left of k), 1-based;
-    // k_spk_merge_strip<RS, true> rebuilds the few nodes it needs from that.
-    ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + chunk] = (uint32_t)cin | (hm << 16);
-    while (lm) {                                                      // one trip per run that ends in this chunk
-        const int k = __builtin_ctz(lm);
-        lm &= lm - 1;
-        const unsigned hb = hm & ((2u << k) - 1u);                    // heads at or left of the end
-        const int h = hb ? x0 + (31 - __builtin_clz(hb)) : hin;
-        const int node = base + cin + __builtin_popcount(hb) - 1;     // (1-based index of this run in the row) - 1
-        const int len = x0 + k - h + 1;
-        label[node] = node;
-        size[node] = len;
-        runs[node] = (uint32_t)h | ((uint32_t)len << 16);
+        if (hl == (TWO ? 31 : 63)) wsum[half][wv] = t;
+        __syncthreads();
+        int run = __builtin_amdgcn_update_dpp(0, t, 0x138, 0xf, 0xf, false);                           // wave_shr:1
+        if (hl == 0) run = 0;
+        for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[half][q]);
+        if (!active) { if (MERGE) continue; else return; }
+        const int base = (f * g.H + y) * g.Ws;
+        const int hin = (run & 0xffff) - 1, cin = run >> 16;         // head and run count carried in from the left
+        // head record of the chunk, one dword instead of eight head columns: (runs that start left of the chunk) | starts << 16
+        // | cand << 24.  The union-find node of a run is its INDEX in the row (dense: a row's labels, sizes and run list are a few
+        // contiguous lines instead of one touched sector per run head -- the count / apply passes and this kernel's own stores
+        // used to scatter over the whole plane): the pixel at bit k belongs to run cin + popcount(starts at or left of k),
+        // 1-based; the merge kernels rebuild the few nodes they need from that.
+        ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + chunk] = (uint32_t)cin | (hm << 16) | (cand << 24);
+        while (lm) {                                                  // one trip per run that ends in this chunk
+            const int k = __builtin_ctz(lm);
+            lm &= lm - 1;
+            const unsigned hb = hm & ((2u << k) - 1u);                // heads at or left of the end
+            const int h = hb ? x0 + (31 - __builtin_clz(hb)) : hin;
+            const int node = base + cin + __builtin_popcount(hb) - 1; // (1-based index of this run in the row) - 1
+            const int len = x0 + k - h + 1;
+            label[node] = node;
+            size[node] = len;
+            runs[node] = (uint32_t)h | ((uint32_t)len << 16);
+        }
+        if (x0 + 8 >= W) rowcnt[f * g.H + y] = cin + __builtin_popcount(hm);
     }
-    if (x0 + 8 >= W) rowcnt[f * g.H + y] = cin + __builtin_popcount(hm);
 }
 
-// Returns true if the head map was written as per-chunk records (k_lrcheck_vec) rather than one int16 per pixel.
-bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
-                    hipStream_t stream, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
-                    int16_t* headmap, int spkDiff)
+// The unions for the contacts k_lrcheck_vec<.., NIT > 1> has found: row pairs (y - 1, y) inside its blocks of `blk` rows
+// (counted from vy0).  One thread = one chunk of row y; all it reads is the row's head records -- most have cand == 0 --
+// and, for the others, the record of the chunk above.  Unions go through the same LDS queue as in k_spk_merge_strip.
+__global__ __launch_bounds__(256) void k_spk_merge_rec(int32_t* label, const uint32_t* heads, int Ws, int H, int vy0, int nrows, int blk, int nch,
+                                                       int32_t* size, int maxSize)
+{
+    constexpr int QCAP = 1024;
+    __shared__ int2 queue[QCAP];
+    __shared__ int qn;
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    // rows r = 1 .. nrows-1 from vy0 with r % blk != 0, numbered densely: j -> r = j + j / (blk - 1) + 1
+    const int inblk = blk - 1, npairs = (nrows / blk) * inblk + max(nrows % blk - 1, 0);
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < npairs * nch) {
+        const int j = idx / nch, chunk = idx - j * nch;
+        const int y = vy0 + j + j / inblk + 1;
+        const int f = blockIdx.y;
+        const size_t rrow = (size_t)(f * H + y) * (Ws >> 3);
+        const uint32_t cb = heads[rrow + chunk];
+        unsigned cand = cb >> 24;
+        if (cand) {
+            const uint32_t ca = heads[rrow - (Ws >> 3) + chunk];
+            const unsigned startA = (ca >> 16) & 0xffu, startB = (cb >> 16) & 0xffu;
+            const int base = (f * H + y) * Ws;
+            while (cand) {
+                const int k = __builtin_ctz(cand);
+                cand &= cand - 1;
+                const unsigned msk = (2u << k) - 1u;
+                const int na = base - Ws + (int)(ca & 0xffffu) + __builtin_popcount(startA & msk) - 1;
+                const int nb = base + (int)(cb & 0xffffu) + __builtin_popcount(startB & msk) - 1;
+                const int slot = atomicAdd(&qn, 1);
+                if (slot < QCAP) queue[slot] = make_int2(na, nb);
+                else uf_union(label, na, nb);
+            }
+        }
+    }
+    __syncthreads();
+    const int total = min(qn, QCAP);
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int a = queue[i].x, b = queue[i].y;
+        if (spk_large_contact(size, a, b, maxSize)) continue;
+        uf_union(label, a, b);
+    }
+}
+
+// Returns 0 if the head map was written per pixel (int16 head columns, nodes = head positions), else (k_lrcheck_vec: one
+// record per chunk, nodes = run indices) the number of consecutive rows, counted from g.vy0, whose pairs the kernel has
+// already merged (1: none).
+int launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
+                   hipStream_t stream, int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                   int16_t* headmap, int spkDiff)
 {
     const int md = disp12MaxDiff * 16;
     const int nrows = g.vy1 - g.vy0;
@@ -547,22 +655,32 @@ bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
     const bool vec = k32 && (g.Ws & 7) == 0 && g.W <= 4096 && lr_rows() == 1 && disp.pitch_e >= (size_t)Wp &&   // that belong to the plane
                      (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2) | (size_t)cost | (size_t)headmap) & 15) == 0;
     if (vec) {
-        const size_t lds = (size_t)Wp * 6 + 16;
-        static const int two_env = env_int("RTDM_LR_TWO_ROWS", 1);   // A/B: 0 = one row per workgroup (round 2)
         const int chunks = Wp >> 3;
+        const auto per_half = [&](int nb) { return (size_t)Wp * 4 + 16 + (size_t)nb * Wp * 2; };
+        static const int two_env = env_int("RTDM_LR_TWO_ROWS", 1);   // A/B: 0 = one row per workgroup (round 2)
+        // row pairs a workgroup walks and merges (1: none -- every pair is left to k_spk_merge_strip, round 3's first form)
+        static const int pairs_env = [] { const int v = env_int("RTDM_LR_PAIRS", 1); return (v == 2 || v == 4 || v == 8) ? v : 1; }();
         // two rows per workgroup where the half-wave form wastes fewer lanes than the whole-wave form and fits 512 threads
         const int waves1 = (chunks + 63) / 64, waves2 = (chunks + 31) / 32;
         const bool two = two_env && waves2 <= 8 && nrows >= 2 && waves2 < 2 * waves1;
         if (two) {
-            const dim3 vblock((unsigned)(waves2 * 64)), vgrid(1, (nrows + 1) / 2, n);
-            if (label) hipLaunchKernelGGL((k_lrcheck_vec<true, true>), vgrid, vblock, 2 * lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-            else       hipLaunchKernelGGL((k_lrcheck_vec<false, true>), vgrid, vblock, 2 * lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-            return label != nullptr;
+            const dim3 vblock((unsigned)(waves2 * 64));
+            const int nit = (label && nrows >= 4) ? pairs_env : 1;
+#define RTDM_LRV(SPK, NIT) hipLaunchKernelGGL((k_lrcheck_vec<SPK, true, NIT>), dim3(1, (nrows + 2 * NIT - 1) / (2 * NIT), n), vblock, \
+                               2 * per_half(NIT > 1 ? 2 : 1), stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff)
+            if (!label) RTDM_LRV(false, 1);
+            else if (nit == 8) RTDM_LRV(true, 8);
+            else if (nit == 4) RTDM_LRV(true, 4);
+            else if (nit == 2) RTDM_LRV(true, 2);
+            else RTDM_LRV(true, 1);
+#undef RTDM_LRV
+            return label ? (nit > 1 ? 2 * nit : 1) : 0;
         }
         const dim3 vblock((unsigned)(waves1 * 64));
-        if (label) hipLaunchKernelGGL((k_lrcheck_vec<true, false>), dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        else       hipLaunchKernelGGL((k_lrcheck_vec<false, false>), dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
-        return label != nullptr;
+        const size_t lds = per_half(1);
+        if (label) hipLaunchKernelGGL((k_lrcheck_vec<true, false, 1>), dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        else       hipLaunchKernelGGL((k_lrcheck_vec<false, false, 1>), dim3(1, nrows, n), vblock, lds, stream, disp, (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff);
+        return label ? 1 : 0;
     } else if (label) {
         const int rr = lr_rows();
         if (k32) { if (rr == 4) RTDM_LR(true, uint16_t, uint32_t, 4); else if (rr == 2) RTDM_LR(true, uint16_t, uint32_t, 2); else RTDM_LR(true, uint16_t, uint32_t, 1); }
@@ -574,7 +692,7 @@ bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12
         else RTDM_LR(false, int32_t, unsigned long long, 1);
     }
 #undef RTDM_LR
-    return false;
+    return 0;
 }
 
 int lrcheck_rows_per_block() { return lr_rows(); }
@@ -684,9 +802,12 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
 // COMPACT: the heads come as one record per 8-column chunk and row (k_lrcheck_vec: carried head + 1 | run starts << 16)
 // instead of one int16 per pixel: a quarter of the head bytes, and "same two runs as the pixel to the left" becomes bit
 // arithmetic (neither pixel of the pair starts a run).
+// RS == 1: the pairs are (y, y + 1) for y = y_lo + k * ystep -- what is left when k_lrcheck_vec has merged the pairs inside
+// blocks of ystep rows itself.
 template <int RS, bool COMPACT>
 __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int Ws, int H,
-                                                         int y_lo, int npairs, int newVal, int maxDiff, const int32_t* size, int maxSize)
+                                                         int y_lo, int npairs, int newVal, int maxDiff, int32_t* size, int maxSize,
+                                                         int ystep)
 {
     // contacts found by the 256 threads are queued in LDS and united afterwards by the first threads, one union per
     // lane: a union is a chain of dependent global accesses, and a wave with a single busy lane stalls as long as a full one
@@ -701,7 +822,7 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     const bool inb = idx < nxb * nstrips;
     const int cidx = inb ? idx : 0;
     const int strip = cidx / nxb, x0 = (cidx % nxb) * 8;
-    const int y = y_lo + strip * RS;
+    const int y = y_lo + strip * (RS == 1 ? ystep : RS);
     const int nr = inb ? min(RS, npairs - strip * RS) : 0;
     const int f = blockIdx.y;
     const int16_t* d = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e + x0;
@@ -795,7 +916,7 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     const int total = min(qn, QCAP);
     for (int i = threadIdx.x; i < total; i += 256) {
         const int a = queue[i].x, b = queue[i].y;
-        if (size[a] > maxSize && size[b] > maxSize) continue;         // two large runs: nothing to learn from uniting them
+        if (spk_large_contact(size, a, b, maxSize)) continue;
         uf_union(label, a, b);
     }
 }
@@ -810,11 +931,12 @@ __global__ __launch_bounds__(256) void k_spk_count(int32_t* label, int32_t* size
     const int cnt = rowcnt[row], base = row * Ws;
     for (int i = threadIdx.x & 15; i < cnt; i += 16) {
         const uint32_t rn = runs[base + i];
-        const int idx = base + (DENSE ? i : (int)(rn & 0xffffu)), len = (int)(rn >> 16);
+        const int idx = base + (DENSE ? i : (int)(rn & 0xffffu));
         const int root = uf_find(label, idx);
         if (root == idx) continue;
         st_relaxed(&label[idx], root);             // roots are final in this launch
-        if (ld_relaxed(&size[root]) <= maxSize) atomicAdd(&size[root], len);
+        // a non-root's size is its run length, or maxSize + 1 if the merge marked it (spk_large_contact): nobody adds to it
+        if (ld_relaxed(&size[root]) <= maxSize) atomicAdd(&size[root], ld_relaxed(&size[idx]));
     }
 }
 
@@ -859,21 +981,31 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
     const int first = y_lo + step - 1;
     const int last = min(y_hi, H) - 2;               // last y with y+1 initialised
     const int npairs = last >= first ? (last - first) / step + 1 : 0;
+    if (compact_heads && step > 1) {               // the contacts inside blocks of `step` rows are in the head records (k_lrcheck_vec<.., NIT > 1>)
+        const int nr = min(y_hi, H) - y_lo, inside = (nr / step) * (step - 1) + max(nr % step - 1, 0), nxb = (W + 7) / 8;
+        if (inside > 0)
+            hipLaunchKernelGGL(k_spk_merge_rec, dim3((inside * nxb + 255) / 256, n), block, 0, stream, label, (const uint32_t*)headmap, Ws, H, y_lo, nr, step, nxb,
+                               size, maxSize);
+    }
     if (npairs > 0) {
         const int nxb = (W + 7) / 8;
         const bool vec = (((size_t)disp.base | (disp.pitch_e * 2) | (disp.frame_e * 2)) & 15) == 0 && (Ws & 7) == 0 &&
                          disp.pitch_e >= (size_t)((W + 7) & ~7);   // a ragged last chunk reads (never writes) padding columns
         dim3 grid((nxb * npairs + 255) / 256, n);
         static const int rs = env_int("RTDM_MERGE_STRIP", 4);
-        if (compact_heads) {                       // written by k_lrcheck_vec, whose alignment conditions imply `vec` and step == 1
+        if (compact_heads && step > 1) {           // k_lrcheck_vec<.., NIT > 1> has found the contacts inside blocks of `step` rows
+            dim3 sgrid((nxb * npairs + 255) / 256, n);
+            hipLaunchKernelGGL((k_spk_merge_strip<1, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, step);
+        } else
+        if (compact_heads) {                       // written by k_lrcheck_vec, whose alignment conditions imply `vec`
             dim3 sgrid((nxb * ((npairs + 3) / 4) + 255) / 256, n);
-            hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
+            hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
         } else
         if (vec && step == 1 && rs > 1) {
             const int RSV = rs >= 8 ? 8 : 4;
             dim3 sgrid((nxb * ((npairs + RSV - 1) / RSV) + 255) / 256, n);
-            if (RSV == 8) hipLaunchKernelGGL((k_spk_merge_strip<8, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
-            else          hipLaunchKernelGGL((k_spk_merge_strip<4, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize);
+            if (RSV == 8) hipLaunchKernelGGL((k_spk_merge_strip<8, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
+            else          hipLaunchKernelGGL((k_spk_merge_strip<4, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
         } else
         if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);

@@ -523,17 +523,18 @@ static int chunk_back(rtdm_bm* bm, const Lane& ln, int n, int W, int H, Plane16W
     StageEvent ev;
     const bool speckle = p.speckleRange >= 0 && p.speckleWindowSize > 0;
     const bool lr = p.disp12MaxDiff >= 0;
-    bool compact_heads = false;
+    int compact_rows = 0;                // > 0: k_lrcheck_vec wrote per-chunk head records and merged blocks of that many rows
     if (lr) {
         stage_begin(bm, RTDM_STAGE_LRCHECK, n, s, &ev);
-        if (speckle) compact_heads = launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, p.speckleRange);
+        if (speckle) compact_rows = launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead,
+                                                   p.speckleRange);
         else         launch_lrcheck(disp, ln.dCost, g, p.disp12MaxDiff, n, s);
         stage_end(bm, s, &ev);
     }
     if (speckle) {
         stage_begin(bm, RTDM_STAGE_SPECKLE, n, s, &ev);
         launch_speckle(disp, ln.dLabel, ln.dSize, ln.dRuns, ln.dRowCnt, ln.dHead, W, g.Ws, H, n, g.filtered, p.speckleWindowSize,
-                       p.speckleRange, lr, lr ? lrcheck_rows_per_block() : 1, g.vy0, g.vy1, s, compact_heads);
+                       p.speckleRange, lr, !lr ? 1 : compact_rows > 0 ? compact_rows : lrcheck_rows_per_block(), g.vy0, g.vy1, s, compact_rows > 0);
         stage_end(bm, s, &ev);
     }
     HIPC(hipGetLastError());

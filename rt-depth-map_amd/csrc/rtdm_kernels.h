@@ -112,10 +112,12 @@ bool launch_search_border2(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, cons
 
 // K3: row-local left-right consistency check (+ column masking to the valid rectangle).  With
 // label != nullptr the speckle filter's per-row init runs on the checked row in the same pass.
-// Returns true if the speckle head map was written as per-chunk records (pass that on to launch_speckle).
-bool launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
-                    hipStream_t stream, int32_t* label = nullptr, int32_t* size = nullptr,
-                    uint32_t* runs = nullptr, int32_t* rowcnt = nullptr, int16_t* headmap = nullptr, int spkDiff = 0);
+// Returns 0 if the speckle head map was written per pixel; otherwise it was written as per-chunk records (compact_heads for
+// launch_speckle) and the value is the number of consecutive rows, from g.vy0, whose pairs the kernel has merged itself
+// (1: none; premerged_rows for launch_speckle).
+int launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12MaxDiff, int n,
+                   hipStream_t stream, int32_t* label = nullptr, int32_t* size = nullptr,
+                   uint32_t* runs = nullptr, int32_t* rowcnt = nullptr, int16_t* headmap = nullptr, int spkDiff = 0);
 
 // K4: speckle filter (connected components under |a-b| <= maxDiff, size <= maxSize removed).
 // label/size/runs/headmap: n*W*H elements each, rowcnt: n*H.  init_done: rows [y_lo,y_hi) were
