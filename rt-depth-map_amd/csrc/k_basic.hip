@@ -998,8 +998,18 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
             hipLaunchKernelGGL((k_spk_merge_strip<1, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, step);
         } else
         if (compact_heads) {                       // written by k_lrcheck_vec, whose alignment conditions imply `vec`
-            dim3 sgrid((nxb * ((npairs + 3) / 4) + 255) / 256, n);
-            hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
+            // Strips of four row pairs read every row 1.25 times instead of twice -- what a batch wants (the kernel streams the
+            // plane) -- but a single frame is 111 workgroups whose threads each work through up to four queued unions, chains of
+            // dependent L2 round trips: 32 us, more than the frame's search.  Small launches take shorter strips: more workgroups,
+            // one union per thread.
+            static const int rs_env = env_int("RTDM_MERGE_RS", 0);    // A/B: 1 / 2 / 4 fixes the strip length
+            int rsc = 4;
+            while (rsc > 1 && (long)((nxb * ((npairs + rsc - 1) / rsc) + 255) / 256) * n < 1024) rsc >>= 1;
+            if (rs_env == 1 || rs_env == 2 || rs_env == 4) rsc = rs_env;
+            dim3 sgrid((nxb * ((npairs + rsc - 1) / rsc) + 255) / 256, n);
+            if (rsc == 4)      hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
+            else if (rsc == 2) hipLaunchKernelGGL((k_spk_merge_strip<2, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
+            else               hipLaunchKernelGGL((k_spk_merge_strip<1, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
         } else
         if (vec && step == 1 && rs > 1) {
             const int RSV = rs >= 8 ? 8 : 4;
