@@ -635,6 +635,222 @@ __global__ __launch_bounds__(256) void k_spk_merge_rec(int32_t* label, const uin
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// k_lrcheck_pk (round 3): k_lrcheck_vec<SPK, true, 1> with TWO COLUMNS PER INSTRUCTION.  k_lrcheck_vec unpacks its eight
+// columns and spends ~73 VALU instructions per pixel on per-column arithmetic and on building bit masks out of compares
+// (v_cmp + v_cndmask + v_or per column and test) -- it is VALU bound.  Here the row stays packed as it arrives (four dwords
+// of two int16 columns): key-slot ADDRESSES are formed in packed u16 arithmetic (LDS byte addresses fit 16 bits), votes and
+// look-ups take one v_perm / one shift per column to split them, the two-sided consistency test is a packed subtraction whose
+// SIGN bits are the verdict, the kill is a v_bfi on the packed row, and only what the run scan needs as bit masks (the
+// validity of the final row, the connected-to-the-left flags) is extracted -- eight flags at a time with two v_perm and two
+// v_dot4_u32_u8.  Measured: 354 instead of 509 VALU instructions on the always-taken path, but packed ops and v_perm issue at
+// 4.4 cycles where most of k_lrcheck_vec's v_and / v_or / v_add / v_sub issue at 2.6: 1.39 -> 1.32 ms per 1024 720p pairs,
+// 0.527 -> 0.487 at 640x480.  NIT > 1 (thread constants formed once for NIT row pairs; RTDM_LR_PK_PAIRS) is SLOWER, with or
+// without the next trip's rows requested a trip ahead (1.51-1.77 ms): 74+ VGPRs instead of 44, and what bounds the kernel is
+// how many short barrier-chained workgroups a CU holds, not its instruction count.  Key slots: key[W] takes the votes nobody may see, key[W + 1] is never written
+// ("no vote").  Needs: costs < 32768 (a slot's cost half is negative only in the empty slot), minD .. minD + D inside
+// int16 / 16, the workgroup's LDS below 64 KB.  Same bytes as k_lrcheck_vec.
+// ---------------------------------------------------------------------------------------------
+typedef short lr_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short lr_u2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t lr_lds_u32;
+__device__ __forceinline__ lr_s2 lr_s(uint32_t v) { return __builtin_bit_cast(lr_s2, v); }
+__device__ __forceinline__ lr_u2 lr_u(uint32_t v) { return __builtin_bit_cast(lr_u2, v); }
+__device__ __forceinline__ uint32_t lr_w(lr_s2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t lr_w(lr_u2 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) { return lr_w(lr_u(a) + lr_u(b)); }
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) { return lr_w(lr_u(a) - lr_u(b)); }
+__device__ __forceinline__ uint32_t pk_subsat_u(uint32_t a, uint32_t b) { return lr_w(__builtin_elementwise_sub_sat(lr_u(a), lr_u(b))); }
+__device__ __forceinline__ uint32_t pk_min_u(uint32_t a, uint32_t b) { return lr_w(__builtin_elementwise_min(lr_u(a), lr_u(b))); }
+__device__ __forceinline__ uint32_t pk_max_i(uint32_t a, uint32_t b) { return lr_w(__builtin_elementwise_max(lr_s(a), lr_s(b))); }
+template <int N> __device__ __forceinline__ uint32_t pk_ashr(uint32_t a) { return lr_w(lr_s(a) >> (short)N); }
+template <int N> __device__ __forceinline__ uint32_t pk_shl(uint32_t a) { return lr_w(lr_u(a) << (unsigned short)N); }
+// 1 in every half of x that is zero, else 0 -- as ONE saturating packed subtraction (written as asm: from min(x, 1) or a
+// compare the compiler builds two v_cmp, two v_cndmask and a v_perm)
+__device__ __forceinline__ uint32_t pk_is_zero(uint32_t x)
+{ uint32_t r; asm("v_pk_sub_u16 %0, 1, %1 op_sel_hi:[0,1] clamp" : "=v"(r) : "v"(x)); return r; }
+__device__ __forceinline__ uint32_t lr_bfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }   // mask ? a : b (v_bfi_b32)
+__device__ __forceinline__ void lr_lds_min(uint32_t addr, uint32_t v)
+{ __hip_atomic_fetch_min((lr_lds_u32*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ uint32_t lr_lds_ld(uint32_t addr) { return *(const lr_lds_u32*)(uintptr_t)addr; }
+// eight flags, one per 16-bit half of h[0..3] (each half 0 or 1), as bits 0..7 in column order
+__device__ __forceinline__ unsigned lr_bits8(const uint32_t (&h)[4])
+{
+    const uint32_t g0 = __builtin_amdgcn_perm(h[1], h[0], 0x06040200u), g1 = __builtin_amdgcn_perm(h[3], h[2], 0x06040200u);
+    return __builtin_amdgcn_udot4(g1, 0x80402010u, __builtin_amdgcn_udot4(g0, 0x08040201u, 0u, false), false);
+}
+
+template <bool SPK, int NIT>
+__global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_t* cost, BMGeom g, int maxDiff16,
+                                                    int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
+                                                    int16_t* headmap, int spkDiff)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int W = g.W, INV = g.filtered;
+    const int Wp = (W + 7) & ~7;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int half = lane >> 5, hl = lane & 31;                       // half-wave = row of the pair (see k_lrcheck_vec<.., TWO>)
+    const int chunk = wv * 32 + hl;
+    const size_t per_half = (size_t)Wp * 4 + 16 + (size_t)Wp * 2;
+    uint32_t* key = (uint32_t*)(smem + (size_t)half * per_half);      // Wp + 4 keys (two used behind the row)
+    int16_t* fin = (int16_t*)(key + Wp + 4);                          // the row after the check (SPK)
+    __shared__ int wsum[2][8];
+    const int x0 = chunk * 8;
+    const int f = blockIdx.z;
+    const int minX1 = max(g.minD + g.D, 0), maxX1 = W + min(g.minD, 0);
+    const uint32_t INVpk = (uint32_t)(INV & 0xffff) * 0x00010001u;
+    // ---- thread constants ----
+    const uint32_t KB = (uint32_t)(uintptr_t)(lr_lds_u32*)key * 0x00010001u;   // LDS byte address of key[0], in both halves
+    const uint32_t TRASH = (uint32_t)W * 0x00010001u, NONE = TRASH + 0x00010001u;   // slot indices
+    uint32_t X[4], VOTEM[4], KEEPM[4];                                // the columns; halves masks (0xffff / 0)
+    const auto in_range = [](int x, int lo, int hi) -> uint32_t { return (x >= lo && x < hi) ? 0xffffu : 0u; };
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int xa = x0 + 2 * k, xb = xa + 1;
+        X[k] = (uint32_t)xa | ((uint32_t)xb << 16);
+        VOTEM[k] = in_range(xa, minX1, maxX1) | (in_range(xb, minX1, maxX1) << 16);
+        KEEPM[k] = in_range(xa, g.vx0, g.vx1) | (in_range(xb, g.vx0, g.vx1) << 16);
+    }
+    // slot index (a negative one wraps to a large u16) -> LDS byte address, anything outside the row -> the slot `lim`
+    const auto slot_addr = [&](uint32_t idx, uint32_t lim) -> uint32_t { return pk_add(pk_shl<2>(pk_min_u(idx, lim)), KB); };
+    const uint32_t Mpk = (uint32_t)maxDiff16 * 0x00010001u;
+    const uint32_t Spk = (uint32_t)spkDiff * 0x00010001u, S2pk = Spk + Spk;
+    if (chunk == 0) { key[Wp] = ~0u; key[Wp + 1] = ~0u; }            // (W == Wp: the two slots lie behind the chunks)
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+        const int ypair = 2 * ((int)blockIdx.y * NIT + it);           // first row of this trip, from vy0
+        if (NIT > 1 && g.vy0 + ypair >= g.vy1) break;                 // (uniform)
+        const int yu = g.vy0 + ypair + half;
+        const bool active = x0 < W && yu < g.vy1;
+        const int y = min(yu, g.vy1 - 1);
+        int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
+        const uint16_t* crow = cost + ((size_t)f * g.H + y) * g.Ws;
+        uint32_t D[4] = {INVpk, INVpk, INVpk, INVpk}, C[4] = {0, 0, 0, 0};
+        if (active) {
+            const uint4 dq = *(const uint4*)(row + x0), cq = *(const uint4*)(crow + x0);
+            D[0] = dq.x; D[1] = dq.y; D[2] = dq.z; D[3] = dq.w; C[0] = cq.x; C[1] = cq.y; C[2] = cq.z; C[3] = cq.w;
+            if (x0 + 8 > W) {                                         // ragged last chunk: padding columns do not exist
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t m = in_range(x0 + 2 * k, 0, W) | (in_range(x0 + 2 * k + 1, 0, W) << 16);
+                    D[k] = lr_bfi(m, D[k], INVpk);
+                }
+            }
+            const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
+            ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
+        }
+        __syncthreads();
+        uint32_t V[4], Dx[4];                                         // halves: is a disparity (0xffff / 0); d + 0x8000
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                V[k] = pk_sub(pk_is_zero(D[k] ^ INVpk), 0x00010001u);
+                Dx[k] = D[k] ^ 0x80008000u;
+                // vote into the slot of x2 = x - ((d + 8) >> 4) with the key cost << 16 | d + 0x8000 (see k_lrcheck_vec).  A column
+                // that may not vote votes with the cost 0xffff: such a key only ever replaces the empty slot's, and reads as empty
+                // (negative cost half) -- no address select; targets outside the row (none inside the vote range) go to key[W]
+                const uint32_t cv = C[k] | ~(V[k] & VOTEM[k]);
+                const uint32_t a = slot_addr(pk_sub(X[k], pk_ashr<4>(pk_add(D[k], 0x00080008u))), TRASH);
+                lr_lds_min(a & 0xffffu, __builtin_amdgcn_perm(cv, Dx[k], 0x05040100u));
+                lr_lds_min(a >> 16, __builtin_amdgcn_perm(cv, Dx[k], 0x07060302u));
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // look-up at x - (d >> 4) (and, where that disagrees, at x - ((d + 15) >> 4)): the slot's voter disagrees iff
+            // |its d - d| > M: the sign of M - |difference|; an empty slot (cost half 0xffff: negative) never disagrees
+            uint32_t bad0[4], any0 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint32_t a = slot_addr(pk_sub(X[k], pk_ashr<4>(D[k])), NONE);
+                const uint32_t qe = lr_lds_ld(a & 0xffffu), qo = lr_lds_ld(a >> 16);
+                const uint32_t df = pk_sub(__builtin_amdgcn_perm(qo, qe, 0x05040100u), Dx[k]);
+                const uint32_t r = pk_sub(Mpk, pk_max_i(df, pk_sub(0u, df)));
+                bad0[k] = r & ~__builtin_amdgcn_perm(qo, qe, 0x07060302u) & V[k] & VOTEM[k] & KEEPM[k];
+                any0 |= bad0[k];
+            }
+            uint32_t Dn[4] = {D[0], D[1], D[2], D[3]};
+            if (__builtin_amdgcn_ballot_w64((any0 & 0x80008000u) != 0) != 0) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t a = slot_addr(pk_sub(X[k], pk_ashr<4>(pk_add(D[k], 0x000f000fu))), NONE);
+                    const uint32_t qe = lr_lds_ld(a & 0xffffu), qo = lr_lds_ld(a >> 16);
+                    const uint32_t df = pk_sub(__builtin_amdgcn_perm(qo, qe, 0x05040100u), Dx[k]);
+                    const uint32_t r = pk_sub(Mpk, pk_max_i(df, pk_sub(0u, df)));
+                    const uint32_t killed = pk_ashr<15>(bad0[k] & r & ~__builtin_amdgcn_perm(qo, qe, 0x07060302u));   // 0xffff where both disagree
+                    Dn[k] = lr_bfi(killed, INVpk, D[k]);
+                }
+            }
+            uint32_t chg = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                Dn[k] = lr_bfi(KEEPM[k], Dn[k], INVpk);               // outside the valid rectangle: always dropped
+                chg |= Dn[k] ^ D[k];
+                D[k] = Dn[k];
+            }
+            if (chg) *(uint4*)(row + x0) = make_uint4(D[0], D[1], D[2], D[3]);
+            if (SPK) *(uint4*)(fin + x0) = make_uint4(D[0], D[1], D[2], D[3]);
+        }
+        if (!SPK) { if (NIT > 1) { __syncthreads(); continue; } else return; }
+        __syncthreads();
+        // ---- speckle init of the finished row (as in k_lrcheck_vec) ----
+        unsigned im = 0, cb = 0;
+        if (active) {
+            const int left = x0 > 0 ? (int)fin[x0 - 1] : INV, right = x0 + 8 < W ? (int)fin[x0 + 8] : INV;
+            uint32_t iz[4], cl[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                iz[k] = pk_is_zero(D[k] ^ INVpk);                     // 1 = NOT a disparity
+                // columns (2k - 1, 2k) and (2k, 2k + 1): |a - b| <= S  <=>  (u16)(a - b + S) <= 2 S
+                const uint32_t prev = __builtin_amdgcn_alignbit(D[k], k ? D[k - 1] : ((uint32_t)left << 16), 16);
+                cl[k] = pk_is_zero(pk_subsat_u(pk_add(pk_sub(D[k], prev), Spk), S2pk));   // 1 = close
+            }
+            im = ~lr_bits8(iz) & 0xffu;
+            // cb bit k (k = 0..8): columns x0+k-1 and x0+k are connected (both disparities, close enough)
+            cb = lr_bits8(cl) & (im & ((im << 1) | (unsigned)(left != INV)));
+            cb |= (unsigned)conn((int)(int16_t)(D[3] >> 16), right, INV, spkDiff) << 8;
+        }
+        const unsigned hm = im & ~cb & 0xffu;                         // run heads
+        unsigned lm = im & ~(cb >> 1) & 0xffu;                        // run ends
+        const int agg = hm ? ((__builtin_popcount(hm) << 16) | (x0 + (31 - __builtin_clz(hm)) + 1)) : 0;
+        int t = agg;
+#define RTDM_SCAN(ctrl, rmask) t = OpHead::f(t, __builtin_amdgcn_update_dpp(0, t, ctrl, rmask, 0xf, false))
+        RTDM_SCAN(0x111, 0xf); RTDM_SCAN(0x112, 0xf); RTDM_SCAN(0x114, 0xf); RTDM_SCAN(0x118, 0xf);   // row_shr:1,2,4,8
+        RTDM_SCAN(0x142, 0xa);                                                                          // row_bcast:15
+#undef RTDM_SCAN
+        if (hl == 31) wsum[half][wv] = t;
+        __syncthreads();
+        int run = __builtin_amdgcn_update_dpp(0, t, 0x138, 0xf, 0xf, false);                           // wave_shr:1
+        if (hl == 0) run = 0;
+        for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[half][q]);
+        if (active) {
+            const int base = (f * g.H + y) * g.Ws;
+            const int hin = (run & 0xffff) - 1, cin = run >> 16;     // head and run count carried in from the left
+            ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + chunk] = (uint32_t)cin | (hm << 16);
+            while (lm) {                                              // one trip per run that ends in this chunk
+                const int k = __builtin_ctz(lm);
+                lm &= lm - 1;
+                const unsigned hb = hm & ((2u << k) - 1u);            // heads at or left of the end
+                const int h = hb ? x0 + (31 - __builtin_clz(hb)) : hin;
+                const int node = base + cin + __builtin_popcount(hb) - 1;
+                const int len = x0 + k - h + 1;
+                label[node] = node;
+                size[node] = len;
+                runs[node] = (uint32_t)h | ((uint32_t)len << 16);
+            }
+            if (x0 + 8 >= W) rowcnt[f * g.H + y] = cin + __builtin_popcount(hm);
+        }
+        // (no barrier here: the next trip's first writes to the keys, the row and wsum lie behind barriers every thread only
+        //  passes after its reads of this trip)
+    }
+}
+
+static bool two_ok_for_pk(const BMGeom& g, int md, int spkDiff)
+{
+    return 2L * g.cap * g.w * g.w < 32768 && md >= 0 && md <= 8192 && spkDiff >= 0 && spkDiff <= 4096 &&
+           g.minD >= -1024 && g.minD + g.D <= 1024 && g.W + 2 < 16384;
+}
+
 // Returns 0 if the head map was written per pixel (int16 head columns, nodes = head positions), else (k_lrcheck_vec: one
 // record per chunk, nodes = run indices) the number of consecutive rows, counted from g.vy0, whose pairs the kernel has
 // already merged (1: none).
@@ -663,6 +879,22 @@ int launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12M
         // two rows per workgroup where the half-wave form wastes fewer lanes than the whole-wave form and fits 512 threads
         const int waves1 = (chunks + 63) / 64, waves2 = (chunks + 31) / 32;
         const bool two = two_env && waves2 <= 8 && nrows >= 2 && waves2 < 2 * waves1;
+        // packed form (k_lrcheck_pk): costs below 32768, every quantity of the consistency / closeness tests inside int16,
+        // LDS byte addresses inside 16 bits
+        static const int pk_env = env_int("RTDM_LR_PACKED", 1);      // A/B: 0 = k_lrcheck_vec; NIT from RTDM_LR_PK_PAIRS
+        static const int pk_pairs = [] { const int v = env_int("RTDM_LR_PK_PAIRS", 1); return (v == 2 || v == 4 || v == 8) ? v : 1; }();
+        const bool pk_ok = pk_env && two_ok_for_pk(g, md, spkDiff) && 2 * per_half(1) + 1024 < 65536;
+        if (two && pk_ok) {
+            const dim3 vblock((unsigned)(waves2 * 64));
+            const int nit = nrows >= 16 ? pk_pairs : 1;
+#define RTDM_LRP(SPK, NIT) hipLaunchKernelGGL((k_lrcheck_pk<SPK, NIT>), dim3(1, (nrows + 2 * NIT - 1) / (2 * NIT), n), vblock, 2 * per_half(1), stream, disp, \
+                               (const uint16_t*)cost, g, md, label, size, runs, rowcnt, headmap, spkDiff)
+#define RTDM_LRP2(NIT) do { if (label) RTDM_LRP(true, NIT); else RTDM_LRP(false, NIT); } while (0)
+            if (nit == 8) RTDM_LRP2(8); else if (nit == 4) RTDM_LRP2(4); else if (nit == 2) RTDM_LRP2(2); else RTDM_LRP2(1);
+#undef RTDM_LRP2
+#undef RTDM_LRP
+            return label ? 1 : 0;
+        }
         if (two) {
             const dim3 vblock((unsigned)(waves2 * 64));
             const int nit = (label && nrows >= 4) ? pairs_env : 1;
