@@ -673,6 +673,10 @@ __device__ __forceinline__ uint32_t lr_bfi(uint32_t mask, uint32_t a, uint32_t b
 __device__ __forceinline__ void lr_lds_min(uint32_t addr, uint32_t v)
 { __hip_atomic_fetch_min((lr_lds_u32*)(uintptr_t)addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ uint32_t lr_lds_ld(uint32_t addr) { return *(const lr_lds_u32*)(uintptr_t)addr; }
+// Barrier for threads that talk through LDS only: waits for the wave's LDS operations, NOT for its global loads and stores
+// (__syncthreads() is a workgroup-scope fence + s_barrier: s_waitcnt vmcnt(0) -- every barrier behind the row's write-back
+// would wait for that store to reach memory, and a trip of k_lrcheck_pk is a chain of four barriers).
+__device__ __forceinline__ void lr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // eight flags, one per 16-bit half of h[0..3] (each half 0 or 1), as bits 0..7 in column order
 __device__ __forceinline__ unsigned lr_bits8(const uint32_t (&h)[4])
 {
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
             const uint4 none = make_uint4(~0u, ~0u, ~0u, ~0u);
             ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
         }
-        __syncthreads();
+        lr_lds_barrier();
         uint32_t V[4], Dx[4];                                         // halves: is a disparity (0xffff / 0); d + 0x8000
         if (active) {
 #pragma unroll
@@ -755,7 +759,7 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
                 lr_lds_min(a >> 16, __builtin_amdgcn_perm(cv, Dx[k], 0x07060302u));
             }
         }
-        __syncthreads();
+        lr_lds_barrier();
         if (active) {
             // look-up at x - (d >> 4) (and, where that disagrees, at x - ((d + 15) >> 4)): the slot's voter disagrees iff
             // |its d - d| > M: the sign of M - |difference|; an empty slot (cost half 0xffff: negative) never disagrees
@@ -791,8 +795,8 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
             if (chg) *(uint4*)(row + x0) = make_uint4(D[0], D[1], D[2], D[3]);
             if (SPK) *(uint4*)(fin + x0) = make_uint4(D[0], D[1], D[2], D[3]);
         }
-        if (!SPK) { if (NIT > 1) { __syncthreads(); continue; } else return; }
-        __syncthreads();
+        if (!SPK) { if (NIT > 1) { lr_lds_barrier(); continue; } else return; }
+        lr_lds_barrier();
         // ---- speckle init of the finished row (as in k_lrcheck_vec) ----
         unsigned im = 0, cb = 0;
         if (active) {
@@ -819,7 +823,7 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
         RTDM_SCAN(0x142, 0xa);                                                                          // row_bcast:15
 #undef RTDM_SCAN
         if (hl == 31) wsum[half][wv] = t;
-        __syncthreads();
+        lr_lds_barrier();
         int run = __builtin_amdgcn_update_dpp(0, t, 0x138, 0xf, 0xf, false);                           // wave_shr:1
         if (hl == 0) run = 0;
         for (int q = 0; q < wv; ++q) run = OpHead::f(run, wsum[half][q]);
