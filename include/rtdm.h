@@ -155,8 +155,9 @@ int rtdm_morph_run_device(rtdm_morph* mf, int n, const uint8_t* d_in, size_t in_
  * 3x3 median, speckle filter), integer arithmetic, bit-exact against that oracle; parity against the library itself is
  * unpinned (OpenCV is not available where this was built). */
 typedef struct rtdm_sgm_params {
-    int blockSize;         /* odd >= 1; 93 * blockSize^2 + P2 must stay <= 32767 (<= 17 at P2 = 2400): beyond that the
-                            * library's 16-bit costs wrap around, which is not reproduced (RTDM_ERR_UNSUPPORTED) */
+    int blockSize;         /* >= 1; an even size runs as the next odd one, as in the library (window = blockSize / 2 either side);
+                            * 93 * window^2 + P2 must stay <= 32767 (window <= 17 at P2 = 2400): beyond that the library's
+                            * 16-bit costs wrap around, which is not reproduced (RTDM_ERR_UNSUPPORTED) */
     int minDisparity;
     int numDisparities;    /* multiple of 16, <= 256 */
     int P1, P2;            /* as the library: P1 <= 0 -> 2, P2 <= 0 -> 5, P2 >= P1 + 1 */

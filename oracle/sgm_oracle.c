@@ -44,7 +44,7 @@
  *   R12 parameters       P1 = P1 > 0 ? P1 : 2, P2 = max(P2 > 0 ? P2 : 5, P1+1).
  * Knowing deviations: (a) the library's CostType is short and wraps above 32767; configurations where
  * 93 * blockSize^2 + P2 can exceed that are refused here (blockSize <= 17 at P2 = 2400) instead of restating the
- * wrap-around; (b) even block sizes are refused (the library takes them and uses an odd window of blockSize/2*2+1);
+ * wrap-around; (b) [round 3: closed] even block sizes run as the library runs them, with the odd window blockSize/2*2+1;
  * (c) for minD != 0 the library precomputes the right image's Birchfield-Tomasi bounds over [minX2, maxX2) only,
  * which does not cover every column the cost loop reads -- the bounds are computed for every column here.
  * Tolerance of the HIP kernels against this file: 0 (integer algorithm).
@@ -260,12 +260,13 @@ int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, con
 {
     if (!p || !L || !R || !disp || W <= 0 || H <= 0) return ORC_ERR_BAD_SIZE;
     const int D = p->numDisparities, minD = p->minDisparity;
-    if (D <= 0 || D % 16 != 0 || p->blockSize < 1 || (p->blockSize & 1) == 0) return ORC_ERR_BAD_PARAM;
+    if (D <= 0 || D % 16 != 0 || p->blockSize < 1) return ORC_ERR_BAD_PARAM;
+    const int wnd = p->blockSize / 2 * 2 + 1;    /* the library never checks the parity: SW2 = SH2 = SADWindowSize / 2, an even size is the next odd one */
     if (p->uniquenessRatio > 100) return ORC_ERR_BAD_PARAM;
     if (p->paths != 0 && p->paths != 5 && p->paths != 8) return ORC_ERR_BAD_PARAM;
     const int P1 = p->P1 > 0 ? p->P1 : 2;                                 /* R12 */
     const int P2 = imax(p->P2 > 0 ? p->P2 : 5, P1 + 1);
-    if (93L * p->blockSize * p->blockSize + P2 > 32767) return ORC_ERR_BAD_PARAM;     /* deviation (a): 16-bit costs would wrap */
+    if (93L * wnd * wnd + P2 > 32767) return ORC_ERR_BAD_PARAM;     /* deviation (a): 16-bit costs would wrap */
     const size_t dstep = dstep_bytes / 2;
     const int INVALID = (minD - 1) * 16;
     const int W1 = (W + imin(minD, 0)) - imax(minD + D, 0);

@@ -1018,9 +1018,12 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     if (!params || !out) return RTDM_ERR_NULL;
     *out = nullptr;
     rtdm_sgm_params p = *params;
-    if (p.numDisparities <= 0 || p.numDisparities % 16 != 0 || p.blockSize < 1 || (p.blockSize & 1) == 0) return RTDM_ERR_BAD_PARAM;
+    if (p.numDisparities <= 0 || p.numDisparities % 16 != 0 || p.blockSize < 1) return RTDM_ERR_BAD_PARAM;
     if (p.uniquenessRatio > 100) return RTDM_ERR_BAD_PARAM;
     if (p.paths != 5 && p.paths != 8) return RTDM_ERR_BAD_PARAM;
+    // cv::StereoSGBM never checks the parity of blockSize: its window is SADWindowSize / 2 either side, an even size runs as
+    // the next odd one (sgbm-sw.cpp:15 hands the caller's blockSize straight through)
+    p.blockSize = p.blockSize / 2 * 2 + 1;
     // what cv::StereoSGBM does with out-of-range knobs (oracle/sgm_oracle.c R6, R9, R12): it coerces them
     if (p.P1 <= 0) p.P1 = 2;
     p.P2 = std::max(p.P2 > 0 ? p.P2 : 5, p.P1 + 1);

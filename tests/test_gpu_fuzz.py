@@ -68,11 +68,11 @@ def test_random_block_matching_configuration(pkg, oracle, synth, seed):
 
 @pytest.mark.parametrize("seed", range(16))
 def test_random_sgm_configuration(pkg, oracle, synth, seed):
-    # cv::StereoSGBM as restated in oracle/sgm_oracle.c: both modes, any odd blockSize the 16-bit costs allow (<= 17 at the
-    # reference's P2), the library's coercion of out-of-range P1 / P2 / uniquenessRatio / disp12MaxDiff
+    # cv::StereoSGBM as restated in oracle/sgm_oracle.c: both modes, any blockSize the 16-bit costs allow (window <= 17 at the
+    # reference's P2; an even size runs as the next odd one), the library's coercion of out-of-range P1 / P2 / uniquenessRatio / disp12MaxDiff
     rng = np.random.default_rng(2000 + seed)
     D = int(rng.choice([16, 32, 64, 128, 192]))
-    bs = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 17]))
+    bs = int(rng.choice([1, 3, 5, 7, 9, 11, 13, 17, 4, 6, 12, 16]))
     minD = int(rng.choice([0, 0, 2, -3]))
     W, H = int(rng.integers(D + 30, D + 150)), int(rng.integers(12, 60))
     kw = dict(blockSize=bs, minDisparity=minD, uniquenessRatio=int(rng.choice([10, 0, 30, -1])),

@@ -62,7 +62,7 @@ def test_kat_constant_image_picks_disparity_zero(oracle):
 def test_parameter_validation(oracle, synth):
     L, R = synth.make_pair(synth.STREAM_SEED, 64, 20, 16)
     # blockSize 19: 93 * 19^2 + 2400 > 32767, where the library's 16-bit costs wrap (deviation (a) of sgm_oracle.c)
-    for bad in (dict(numDisparities=20), dict(blockSize=4), dict(uniquenessRatio=101), dict(blockSize=19)):
+    for bad in (dict(numDisparities=20), dict(blockSize=0), dict(uniquenessRatio=101), dict(blockSize=19), dict(blockSize=18)):
         kw = dict(numDisparities=16); kw.update(bad)
         with pytest.raises(ValueError):
             oracle.sgm_compute(L, R, **kw)
@@ -70,6 +70,16 @@ def test_parameter_validation(oracle, synth):
     a = oracle.sgm_compute(L, R, numDisparities=16, P1=0, P2=0)
     assert np.array_equal(a, oracle.sgm_compute(L, R, numDisparities=16, P1=2, P2=5))
     assert np.array_equal(oracle.sgm_compute(L, R, numDisparities=16, P1=10, P2=10), oracle.sgm_compute(L, R, numDisparities=16, P1=10, P2=11))
+
+
+def test_even_block_size_is_the_next_odd_one(oracle, synth):
+    # cv::StereoSGBM never checks the parity of SADWindowSize: SW2 = SH2 = SADWindowSize / 2 (sgbm-sw.cpp:15 passes the
+    # caller's blockSize through unchanged); the second implementation (tests/bruteforce.py: r = blockSize // 2) agrees
+    L, R = synth.make_pair(synth.STREAM_SEED + 3, 72, 24, 16)
+    for even in (4, 8):
+        a = oracle.sgm_compute(L, R, numDisparities=16, blockSize=even)
+        assert np.array_equal(a, oracle.sgm_compute(L, R, numDisparities=16, blockSize=even + 1))
+        assert np.array_equal(a, bf.sgm(L, R, numDisparities=16, blockSize=even))
 
 
 def test_kat_left_right_check_cannot_be_switched_off(oracle, synth):
