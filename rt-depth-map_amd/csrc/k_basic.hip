@@ -647,7 +647,9 @@ __global__ __launch_bounds__(256) void k_spk_merge_rec(int32_t* label, const uin
 // 4.4 cycles where most of k_lrcheck_vec's v_and / v_or / v_add / v_sub issue at 2.6: 1.39 -> 1.32 ms per 1024 720p pairs,
 // 0.527 -> 0.487 at 640x480.  NIT > 1 (thread constants formed once for NIT row pairs; RTDM_LR_PK_PAIRS) is SLOWER, with or
 // without the next trip's rows requested a trip ahead (1.51-1.77 ms): 74+ VGPRs instead of 44, and what bounds the kernel is
-// how many short barrier-chained workgroups a CU holds, not its instruction count.  Key slots: key[W] takes the votes nobody may see, key[W + 1] is never written
+// how many short barrier-chained workgroups a CU holds, not its instruction count (also with barriers that do not wait
+// for global memory: 1.79 ms).  Timing-only ablations (LRPK_ABL, profiles/r03_lrcheck_ablation.txt): loading the two planes and
+// resetting the keys alone takes 0.59 ms -- 3.8 GB at 6.4 TB/s, the HBM floor; the speckle init costs 0.25 ms, the votes 0.09.  Key slots: key[W] takes the votes nobody may see, key[W + 1] is never written
 // ("no vote").  Needs: costs < 32768 (a slot's cost half is negative only in the empty slot), minD .. minD + D inside
 // int16 / 16, the workgroup's LDS below 64 KB.  Same bytes as k_lrcheck_vec.
 // ---------------------------------------------------------------------------------------------
@@ -684,6 +686,9 @@ __device__ __forceinline__ unsigned lr_bits8(const uint32_t (&h)[4])
     return __builtin_amdgcn_udot4(g1, 0x80402010u, __builtin_amdgcn_udot4(g0, 0x08040201u, 0u, false), false);
 }
 
+#ifndef LRPK_ABL          // timing-only ablations of k_lrcheck_pk (variant builds, wrong results): 1 no votes, 2 no look-ups, 3 no speckle
+#define LRPK_ABL 0        // init, 4 no run records, 5 no row loads, 6 nothing behind the loads
+#endif
 template <bool SPK, int NIT>
 __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_t* cost, BMGeom g, int maxDiff16,
                                                     int32_t* label, int32_t* size, uint32_t* runs, int32_t* rowcnt,
@@ -708,12 +713,16 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
     const uint32_t TRASH = (uint32_t)W * 0x00010001u, NONE = TRASH + 0x00010001u;   // slot indices
     uint32_t X[4], VOTEM[4], KEEPM[4];                                // the columns; halves masks (0xffff / 0)
     const auto in_range = [](int x, int lo, int hi) -> uint32_t { return (x >= lo && x < hi) ? 0xffffu : 0u; };
+    // lo <= x < hi  <=>  (u16)(x - lo) < hi - lo  <=>  (hi - lo) -sat (u16)(x - lo) != 0: four packed instructions per pair of
+    // columns (as scalar compares and selects the masks were a third of the kernel's prologue -- which a thread pays per row)
+    const uint32_t vlo = (uint32_t)(minX1 & 0xffff) * 0x00010001u, vhl = (uint32_t)max(maxX1 - minX1, 0) * 0x00010001u;
+    const uint32_t klo = (uint32_t)(g.vx0 & 0xffff) * 0x00010001u, khl = (uint32_t)max(g.vx1 - g.vx0, 0) * 0x00010001u;
+    const uint32_t X0 = (uint32_t)x0 * 0x00010001u + 0x00010000u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const int xa = x0 + 2 * k, xb = xa + 1;
-        X[k] = (uint32_t)xa | ((uint32_t)xb << 16);
-        VOTEM[k] = in_range(xa, minX1, maxX1) | (in_range(xb, minX1, maxX1) << 16);
-        KEEPM[k] = in_range(xa, g.vx0, g.vx1) | (in_range(xb, g.vx0, g.vx1) << 16);
+        X[k] = X0 + (uint32_t)k * 0x00020002u;
+        VOTEM[k] = pk_sub(pk_is_zero(pk_subsat_u(vhl, pk_sub(X[k], vlo))), 0x00010001u);
+        KEEPM[k] = pk_sub(pk_is_zero(pk_subsat_u(khl, pk_sub(X[k], klo))), 0x00010001u);
     }
     // slot index (a negative one wraps to a large u16) -> LDS byte address, anything outside the row -> the slot `lim`
     const auto slot_addr = [&](uint32_t idx, uint32_t lim) -> uint32_t { return pk_add(pk_shl<2>(pk_min_u(idx, lim)), KB); };
@@ -724,14 +733,17 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
     for (int it = 0; it < NIT; ++it) {
         const int ypair = 2 * ((int)blockIdx.y * NIT + it);           // first row of this trip, from vy0
         if (NIT > 1 && g.vy0 + ypair >= g.vy1) break;                 // (uniform)
-        const int yu = g.vy0 + ypair + half;
-        const bool active = x0 < W && yu < g.vy1;
-        const int y = min(yu, g.vy1 - 1);
-        int16_t* row = disp.base + (size_t)f * disp.frame_e + (size_t)y * disp.pitch_e;
-        const uint16_t* crow = cost + ((size_t)f * g.H + y) * g.Ws;
+        const int y0 = g.vy0 + ypair, y = y0 + half;                  // (row addresses: wave-uniform part + the half's row step)
+        const bool active = x0 < W && y < g.vy1;
+        int16_t* row = disp.base + ((size_t)f * disp.frame_e + (size_t)y0 * disp.pitch_e) + (half ? (uint32_t)disp.pitch_e : 0u);
+        [[maybe_unused]] const uint16_t* crow = cost + ((size_t)f * g.H + y0) * g.Ws + (half ? (uint32_t)g.Ws : 0u);
         uint32_t D[4] = {INVpk, INVpk, INVpk, INVpk}, C[4] = {0, 0, 0, 0};
         if (active) {
+#if LRPK_ABL == 5
+            const uint4 dq = make_uint4(0x00200020u + lane, 0x00300030u, 0x00400040u + it, 0x00200020u), cq = make_uint4(lane, 5, 6, 7);
+#else
             const uint4 dq = *(const uint4*)(row + x0), cq = *(const uint4*)(crow + x0);
+#endif
             D[0] = dq.x; D[1] = dq.y; D[2] = dq.z; D[3] = dq.w; C[0] = cq.x; C[1] = cq.y; C[2] = cq.z; C[3] = cq.w;
             if (x0 + 8 > W) {                                         // ragged last chunk: padding columns do not exist
 #pragma unroll
@@ -744,6 +756,10 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
             ((uint4*)(key + x0))[0] = none; ((uint4*)(key + x0))[1] = none;
         }
         lr_lds_barrier();
+#if LRPK_ABL == 6
+        if (active && (D[0] ^ C[1]) == 0x12345678u) row[x0] = 1;
+        continue;
+#endif
         uint32_t V[4], Dx[4];                                         // halves: is a disparity (0xffff / 0); d + 0x8000
         if (active) {
 #pragma unroll
@@ -755,8 +771,12 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
                 // (negative cost half) -- no address select; targets outside the row (none inside the vote range) go to key[W]
                 const uint32_t cv = C[k] | ~(V[k] & VOTEM[k]);
                 const uint32_t a = slot_addr(pk_sub(X[k], pk_ashr<4>(pk_add(D[k], 0x00080008u))), TRASH);
+#if LRPK_ABL == 1
+                if ((a ^ cv) == 0x12345678u) key[0] = a;
+#else
                 lr_lds_min(a & 0xffffu, __builtin_amdgcn_perm(cv, Dx[k], 0x05040100u));
                 lr_lds_min(a >> 16, __builtin_amdgcn_perm(cv, Dx[k], 0x07060302u));
+#endif
             }
         }
         lr_lds_barrier();
@@ -767,7 +787,11 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const uint32_t a = slot_addr(pk_sub(X[k], pk_ashr<4>(D[k])), NONE);
+#if LRPK_ABL == 2
+                const uint32_t qe = a, qo = ~a;
+#else
                 const uint32_t qe = lr_lds_ld(a & 0xffffu), qo = lr_lds_ld(a >> 16);
+#endif
                 const uint32_t df = pk_sub(__builtin_amdgcn_perm(qo, qe, 0x05040100u), Dx[k]);
                 const uint32_t r = pk_sub(Mpk, pk_max_i(df, pk_sub(0u, df)));
                 bad0[k] = r & ~__builtin_amdgcn_perm(qo, qe, 0x07060302u) & V[k] & VOTEM[k] & KEEPM[k];
@@ -799,7 +823,7 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
         lr_lds_barrier();
         // ---- speckle init of the finished row (as in k_lrcheck_vec) ----
         unsigned im = 0, cb = 0;
-        if (active) {
+        if (active && LRPK_ABL != 3) {
             const int left = x0 > 0 ? (int)fin[x0 - 1] : INV, right = x0 + 8 < W ? (int)fin[x0 + 8] : INV;
             uint32_t iz[4], cl[4];
 #pragma unroll
@@ -831,7 +855,7 @@ __global__ __launch_bounds__(512) void k_lrcheck_pk(Plane16W disp, const uint16_
             const int base = (f * g.H + y) * g.Ws;
             const int hin = (run & 0xffff) - 1, cin = run >> 16;     // head and run count carried in from the left
             ((uint32_t*)headmap)[(size_t)(f * g.H + y) * (g.Ws >> 3) + chunk] = (uint32_t)cin | (hm << 16);
-            while (lm) {                                              // one trip per run that ends in this chunk
+            while (lm && LRPK_ABL != 4) {                             // one trip per run that ends in this chunk
                 const int k = __builtin_ctz(lm);
                 lm &= lm - 1;
                 const unsigned hb = hm & ((2u << k) - 1u);            // heads at or left of the end
