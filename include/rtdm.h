@@ -155,9 +155,11 @@ int rtdm_morph_run_device(rtdm_morph* mf, int n, const uint8_t* d_in, size_t in_
  * 3x3 median, speckle filter), integer arithmetic, bit-exact against that oracle; parity against the library itself is
  * unpinned (OpenCV is not available where this was built). */
 typedef struct rtdm_sgm_params {
-    int blockSize;         /* >= 1; an even size runs as the next odd one, as in the library (window = blockSize / 2 either side);
-                            * 93 * window^2 + P2 must stay <= 32767 (window <= 17 at P2 = 2400): beyond that the library's
-                            * 16-bit costs wrap around, which is not reproduced (RTDM_ERR_UNSUPPORTED) */
+    int blockSize;         /* 1..255; an even size runs as the next odd one, as in the library (window = blockSize / 2 either
+                            * side).  Where 93 * window^2 + P2 > 32767 (window > 17 at P2 = 2400) a block cost + P2 CAN pass
+                            * 32767, where the library's 16-bit costs wrap around -- which is not reproduced: a frame in which
+                            * it does is refused by the compute call (RTDM_ERR_UNSUPPORTED; it takes nearly every pixel of a
+                            * window at the maximum pixel cost), and rtdm_sgm_compute_device synchronises its stream to tell */
     int minDisparity;
     int numDisparities;    /* multiple of 16, <= 256 */
     int P1, P2;            /* as the library: P1 <= 0 -> 2, P2 <= 0 -> 5, P2 >= P1 + 1 */

@@ -92,7 +92,7 @@ def lib():
         L.orc_sgm_pixel_cost.argtypes = [u8p, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
         L.orc_sgm_pixel_cost.restype = None
         L.orc_sgm_block_cost.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
-        L.orc_sgm_block_cost.restype = None
+        L.orc_sgm_block_cost.restype = C.c_uint32
         L.orc_sgm_aggregate.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u16p]
         L.orc_sgm_aggregate.restype = None
         L.orc_sgm_aggregate_paths.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u16p]

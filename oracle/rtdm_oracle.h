@@ -82,7 +82,8 @@ typedef struct orc_bm_params {
 enum {
     ORC_OK = 0,
     ORC_ERR_BAD_PARAM = -1,
-    ORC_ERR_BAD_SIZE = -2
+    ORC_ERR_BAD_SIZE = -2,
+    ORC_ERR_COST_OVERFLOW = -3      /* StereoSGBM: block cost + P2 > 32767 somewhere in the frame (the library's 16-bit costs would wrap) */
 };
 
 /* X-Sobel prefilter (OpenCV prefilterXSobel): clip(sobel_x, -cap, cap) + cap. */
@@ -140,7 +141,7 @@ typedef struct orc_sgm_params {
 
 void orc_sgm_pixel_cost(const uint8_t* L, size_t lstep, const uint8_t* R, size_t rstep, int W, int H,
                         int minD, int D, uint16_t* cost);
-void orc_sgm_block_cost(const uint16_t* pix, int W1, int H, int D, int blockSize, uint16_t* C);
+uint32_t orc_sgm_block_cost(const uint16_t* pix, int W1, int H, int D, int blockSize, uint16_t* C);   /* -> the largest block cost */
 void orc_sgm_aggregate(const uint16_t* C, int W1, int H, int D, int P1, int P2, uint16_t* S);            /* 8 paths */
 void orc_sgm_aggregate_paths(const uint16_t* C, int W1, int H, int D, int P1, int P2, int paths, uint16_t* S);
 void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int uniquenessRatio, int disp12MaxDiff,

@@ -42,9 +42,9 @@
  *   R10 median           medianBlur(disp, disp, 3): 3x3 median of the int16 map, coordinates clamped (BORDER_REPLICATE).
  *   R11 speckle          if speckleWindowSize > 0: filterSpeckles(disp, (minD-1)*16, window, 16 * speckleRange).
  *   R12 parameters       P1 = P1 > 0 ? P1 : 2, P2 = max(P2 > 0 ? P2 : 5, P1+1).
- * Knowing deviations: (a) the library's CostType is short and wraps above 32767; configurations where
- * 93 * blockSize^2 + P2 can exceed that are refused here (blockSize <= 17 at P2 = 2400) instead of restating the
- * wrap-around; (b) [round 3: closed] even block sizes run as the library runs them, with the odd window blockSize/2*2+1;
+ * Knowing deviations: (a) the library's CostType is short and wraps above 32767; a frame whose largest block cost + P2
+ * exceeds that is refused (ORC_ERR_COST_OVERFLOW) instead of restating the wrap-around -- impossible for windows <= 17
+ * at P2 = 2400 (93 * 17^2 + 2400 < 32767), data dependent above; (b) [round 3: closed] even block sizes run as the library runs them, with the odd window blockSize/2*2+1;
  * (c) for minD != 0 the library precomputes the right image's Birchfield-Tomasi bounds over [minX2, maxX2) only,
  * which does not cover every column the cost loop reads -- the bounds are computed for every column here.
  * Tolerance of the HIP kernels against this file: 0 (integer algorithm).
@@ -120,8 +120,10 @@ void orc_sgm_pixel_cost(const uint8_t* L, size_t lstep, const uint8_t* R, size_t
     free(ir); free(il); free(gr); free(gl);
 }
 
-void orc_sgm_block_cost(const uint16_t* pix, int W, int H, int D, int blockSize, uint16_t* C)
+/* Returns the largest block cost (a caller that needs 16-bit path costs checks it against 32767 - P2: deviation (a)). */
+uint32_t orc_sgm_block_cost(const uint16_t* pix, int W, int H, int D, int blockSize, uint16_t* C)
 {
+    uint32_t cmax = 0;
     const int r = blockSize / 2;
     /* separable box sum with clamped coordinates */
     uint32_t* tmp = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)W * H * D);
@@ -138,8 +140,10 @@ void orc_sgm_block_cost(const uint16_t* pix, int W, int H, int D, int blockSize,
                 uint32_t s = 0;
                 for (int k = -r; k <= r; ++k) s += tmp[((size_t)iclamp(y + k, 0, H - 1) * W + x) * D + d];
                 C[((size_t)y * W + x) * D + d] = (uint16_t)s;
+                if (s > cmax) cmax = s;
             }
     free(tmp);
+    return cmax;
 }
 
 /* S += L_r for one direction (dx, dy) */
@@ -261,12 +265,12 @@ int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, con
     if (!p || !L || !R || !disp || W <= 0 || H <= 0) return ORC_ERR_BAD_SIZE;
     const int D = p->numDisparities, minD = p->minDisparity;
     if (D <= 0 || D % 16 != 0 || p->blockSize < 1) return ORC_ERR_BAD_PARAM;
-    const int wnd = p->blockSize / 2 * 2 + 1;    /* the library never checks the parity: SW2 = SH2 = SADWindowSize / 2, an even size is the next odd one */
+    /* the library never checks the parity: SW2 = SH2 = SADWindowSize / 2, an even size is the next odd one */
+    if (p->blockSize / 2 * 2 + 1 > 255) return ORC_ERR_BAD_PARAM;
     if (p->uniquenessRatio > 100) return ORC_ERR_BAD_PARAM;
     if (p->paths != 0 && p->paths != 5 && p->paths != 8) return ORC_ERR_BAD_PARAM;
     const int P1 = p->P1 > 0 ? p->P1 : 2;                                 /* R12 */
     const int P2 = imax(p->P2 > 0 ? p->P2 : 5, P1 + 1);
-    if (93L * wnd * wnd + P2 > 32767) return ORC_ERR_BAD_PARAM;     /* deviation (a): 16-bit costs would wrap */
     const size_t dstep = dstep_bytes / 2;
     const int INVALID = (minD - 1) * 16;
     const int W1 = (W + imin(minD, 0)) - imax(minD + D, 0);
@@ -280,7 +284,13 @@ int orc_sgm_compute(const orc_sgm_params* p, const uint8_t* L, size_t lstep, con
     uint16_t* S = (uint16_t*)malloc(vol * 2);
     int16_t* raw = (int16_t*)malloc(sizeof(int16_t) * (size_t)W * H);
     orc_sgm_pixel_cost(L, lstep, R, rstep, W, H, minD, D, pix);
-    orc_sgm_block_cost(pix, W1, H, D, p->blockSize, C);
+    /* deviation (a): a path cost is at most block cost + P2; where that passes 32767 the library's short arithmetic wraps,
+     * which is not restated -- such a FRAME is refused (round 3; until then every window > 17 was refused at P2 = 2400,
+     * although a block cost near its bound 93 * window^2 needs every pixel of the window at the maximum pixel cost) */
+    if ((long)orc_sgm_block_cost(pix, W1, H, D, p->blockSize, C) + P2 > 32767) {
+        free(raw); free(S); free(C); free(pix);
+        return ORC_ERR_COST_OVERFLOW;
+    }
     orc_sgm_aggregate_paths(C, W1, H, D, P1, P2, p->paths == 5 ? 5 : 8, S);
     orc_sgm_select(S, W, H, D, minD, p->uniquenessRatio, p->disp12MaxDiff, raw, (size_t)W);
     orc_median3x3_s16(raw, (size_t)W, disp, dstep, W, H);                 /* R10 */

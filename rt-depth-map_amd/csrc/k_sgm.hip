@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_sgm_pix(const uint2* bl, const uint2* b
 // block cost: thread = (x, four consecutive d); walks down a strip of rows keeping the last 2R+1 horizontal sums in
 // registers, so every pixel-cost element is read (2R+1) times instead of (2R+1)^2 times
 template <int R>
-__global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C, SGMGeom g, int rows_per_strip)
+__global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C, SGMGeom g, int rows_per_strip, int cost_limit, int32_t* ovf)
 {
     const int dq = g.D >> 2;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D/4
@@ -150,12 +150,47 @@ __global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C
             if (y + k < y1) {
                 *(uint2*)(out + (size_t)(y + k) * g.W1 * g.D) =
                     make_uint2((uint32_t)sum[0] | ((uint32_t)sum[1] << 16), (uint32_t)sum[2] | ((uint32_t)sum[3] << 16));
+                if (cost_limit > 0 && max(max(sum[0], sum[1]), max(sum[2], sum[3])) > cost_limit) *ovf = 1;
                 const Sum4 h = hsum(y + k + R + 1);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sum[j] += h.v[j] - ring[k].v[j]; }
                 ring[k] = h;
             }
         }
+    }
+}
+
+// Any window (R > 8: the register ring of k_sgm_box<R> would not fit): the running vertical sum gains the entering row's
+// horizontal sum and loses the leaving row's, both recomputed -- 2 (2R + 1) loads per output instead of 2R + 1.  Sums are
+// 32-bit; a block cost above cost_limit (> 0) sets *ovf and is stored truncated (the caller refuses the frame).
+__global__ __launch_bounds__(256) void k_sgm_box_any(const uint8_t* pix, uint16_t* C, SGMGeom g, int R, int rows_per_strip, int cost_limit, int32_t* ovf)
+{
+    const int dq = g.D >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;          // over W1 * D/4
+    if (idx >= (size_t)g.W1 * dq) return;
+    const int d = (int)(idx % dq) * 4, xi = (int)(idx / dq);
+    const int f = blockIdx.z;
+    const int y0 = blockIdx.y * rows_per_strip, y1 = min(y0 + rows_per_strip, g.H);
+    const uint8_t* base = pix + (size_t)f * g.H * g.W1 * g.D + d;
+    struct Sum4 { int v[4]; };
+    const auto hsum = [&](int y) -> Sum4 {
+        const uint8_t* row = base + (size_t)min(max(y, 0), g.H - 1) * g.W1 * g.D;
+        Sum4 s = {{0, 0, 0, 0}};
+        for (int k = -R; k <= R; ++k) {
+            const uint32_t w = *(const uint32_t*)(row + (size_t)min(max(xi + k, 0), g.W1 - 1) * g.D);
+            s.v[0] += w & 0xff; s.v[1] += (w >> 8) & 0xff; s.v[2] += (w >> 16) & 0xff; s.v[3] += w >> 24;
+        }
+        return s;
+    };
+    int sum[4] = {0, 0, 0, 0};
+    for (int k = -R; k <= R; ++k) { const Sum4 h = hsum(y0 + k); for (int j = 0; j < 4; ++j) sum[j] += h.v[j]; }
+    uint16_t* out = C + (((size_t)f * g.H) * g.W1 + xi) * g.D + d;
+    for (int y = y0; y < y1; ++y) {
+        *(uint2*)(out + (size_t)y * g.W1 * g.D) =
+            make_uint2((uint32_t)(sum[0] & 0xffff) | ((uint32_t)sum[1] << 16), (uint32_t)(sum[2] & 0xffff) | ((uint32_t)sum[3] << 16));
+        if (cost_limit > 0 && max(max(sum[0], sum[1]), max(sum[2], sum[3])) > cost_limit) *ovf = 1;
+        const Sum4 a = hsum(y + R + 1), b = hsum(y - R);
+        for (int j = 0; j < 4; ++j) sum[j] += a.v[j] - b.v[j];
     }
 }
 
@@ -541,7 +576,8 @@ static void launch_select(int nch, dim3 grid, size_t lds, hipStream_t stream, co
 }
 
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
-                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream)
+                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream,
+                int cost_limit)
 {
     dim3 blk(256);
     hipLaunchKernelGGL(k_sgm_bounds, dim3((g.W + 255) / 256, g.H, 2 * n), blk, 0, stream, L, R, (uint2*)b.gl, (uint2*)b.gr, g.W, g.H, n);
@@ -550,10 +586,10 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     {
         const int rps = 48, strips = (g.H + rps - 1) / rps;
         const dim3 bgrid(nxd, strips, n);
-        switch (blockSize / 2) {                      // blockSize <= 17 (rtdm_sgm_create: 93 * blockSize^2 + P2 <= 32767)
-#define RTDM_BOX(RR) case RR: hipLaunchKernelGGL(k_sgm_box<RR>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
-            RTDM_BOX(0) RTDM_BOX(1) RTDM_BOX(2) RTDM_BOX(3) RTDM_BOX(4) RTDM_BOX(5) RTDM_BOX(6) RTDM_BOX(7)
-            default: hipLaunchKernelGGL(k_sgm_box<8>, bgrid, blk, 0, stream, b.pix, b.C, g, rps); break;
+        switch (blockSize / 2) {                      // windows <= 17: the row sums of a strip stay in registers
+#define RTDM_BOX(RR) case RR: hipLaunchKernelGGL(k_sgm_box<RR>, bgrid, blk, 0, stream, b.pix, b.C, g, rps, cost_limit, b.ovf); break;
+            RTDM_BOX(0) RTDM_BOX(1) RTDM_BOX(2) RTDM_BOX(3) RTDM_BOX(4) RTDM_BOX(5) RTDM_BOX(6) RTDM_BOX(7) RTDM_BOX(8)
+            default: hipLaunchKernelGGL(k_sgm_box_any, bgrid, blk, 0, stream, b.pix, b.C, g, blockSize / 2, rps, cost_limit, b.ovf); break;
 #undef RTDM_BOX
         }
     }

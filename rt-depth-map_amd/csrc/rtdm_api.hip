@@ -1004,7 +1004,21 @@ struct rtdm_sgm {
     uint8_t *dInL, *dInR;
     int16_t* dOut;
     SGMBuffers b;
+    int cost_limit;                // > 0 (windows > 17 at P2 = 2400): a block cost above it would wrap the library's 16-bit path costs
+    int32_t* hOvf;                 // page-locked copy of b.ovf
 };
+
+// windows whose block cost + P2 can pass 32767: the frame is refused if it does (what is not restated is the wrap-around)
+static int sgm_overflow_check(rtdm_sgm* sg, hipStream_t s)
+{
+    if (!sg->cost_limit) return RTDM_OK;
+    HIPC(hipMemcpyAsync(sg->hOvf, sg->b.ovf, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPC(hipStreamSynchronize(s));
+    if (!*sg->hOvf) return RTDM_OK;
+    HIPC(hipMemsetAsync(sg->b.ovf, 0, sizeof(int32_t), s));
+    g_hip_err = "StereoSGBM: a block cost + P2 exceeds 32767 in this frame (the library's 16-bit costs would wrap)";
+    return RTDM_ERR_UNSUPPORTED;
+}
 
 void rtdm_sgm_default_params(rtdm_sgm_params* p, int numDisparities, int blockSize)
 {
@@ -1032,13 +1046,17 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     if (max_width <= 0 || max_height <= 0 || max_batch <= 0) return RTDM_ERR_BAD_SIZE;
     if (p.numDisparities > 256 || max_width > 4096) return RTDM_ERR_UNSUPPORTED;
     // 16-bit costs: a path cost is at most block cost + P2 (pixel cost <= 30 + 63); above 32767 the library's short
-    // arithmetic wraps, which is not restated (blockSize <= 17 at P2 = 2400)
-    if (93L * p.blockSize * p.blockSize + p.P2 > 32767) return RTDM_ERR_UNSUPPORTED;
+    // arithmetic wraps, which is not restated: windows that CAN get there (> 17 at P2 = 2400) run with a check of the block
+    // costs and refuse the frame that does (RTDM_ERR_UNSUPPORTED from the compute call; it takes nearly every pixel of a
+    // window at the maximum pixel cost)
+    if (p.blockSize > 255 || p.P2 > 32000) return RTDM_ERR_UNSUPPORTED;
+    const int cost_limit = 93L * p.blockSize * p.blockSize + p.P2 > 32767 ? 32767 - p.P2 : 0;
     int rc = use_device(device);
     if (rc) return rc;
     rtdm_sgm* sg = new (std::nothrow) rtdm_sgm();
     if (!sg) return RTDM_ERR_NOMEM;
     sg->p = p; sg->maxW = max_width; sg->maxH = max_height; sg->maxB = max_batch; sg->device = device;
+    sg->cost_limit = cost_limit;
     const size_t px = (size_t)max_width * max_height * max_batch;
     const size_t vol = px * p.numDisparities;
     hipError_t e = hipStreamCreateWithFlags(&sg->stream, hipStreamNonBlocking);
@@ -1048,6 +1066,9 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     const size_t sizes[] = {px, px, px * 2, px * 8, px * 8, vol, vol * 2, vol * 2, px * 4, px * 4, px * 4,
                             (size_t)max_batch * max_height * 4, px * 2};
     for (int i = 0; i < 13 && e == hipSuccess; ++i) e = hipMalloc(ptrs[i], sizes[i]);
+    if (e == hipSuccess) e = hipMalloc((void**)&sg->b.ovf, sizeof(int32_t));
+    if (e == hipSuccess) e = hipMemset(sg->b.ovf, 0, sizeof(int32_t));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&sg->hOvf, sizeof(int32_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         g_hip_err = std::string("rtdm_sgm_create: ") + hipGetErrorString(e);
         rtdm_sgm_destroy(sg);
@@ -1065,6 +1086,8 @@ void rtdm_sgm_destroy(rtdm_sgm* sg)
     void* bufs[] = {sg->dInL, sg->dInR, sg->dOut, sg->b.gl, sg->b.gr, sg->b.pix, sg->b.C, sg->b.S, sg->b.label, sg->b.size,
                     sg->b.runs, sg->b.rowcnt, sg->b.headmap};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (sg->b.ovf) (void)hipFree(sg->b.ovf);
+    if (sg->hOvf) (void)hipHostFree(sg->hOvf);
     if (sg->stream) (void)hipStreamDestroy(sg->stream);
     delete sg;
 }
@@ -1078,7 +1101,7 @@ static int sgm_chunk(rtdm_sgm* sg, int n, Plane8 L, Plane8 R, int W, int H, Plan
     g.W1 = (W + std::min(g.minD, 0)) - g.x0;
     if (g.W1 <= 0) { launch_fill16(disp, 0, W, 0, H, n, (g.minD - 1) * 16, s); return RTDM_OK; }
     launch_sgm(L, R, disp, g, sg->b, p.blockSize, p.P1, p.P2, p.uniquenessRatio, p.disp12MaxDiff, p.speckleWindowSize,
-               p.speckleRange, p.paths, n, s);
+               p.speckleRange, p.paths, n, s, sg->cost_limit);
     HIPC(hipGetLastError());
     return RTDM_OK;
 }
@@ -1099,7 +1122,7 @@ int rtdm_sgm_compute_device(rtdm_sgm* sg, int n, const uint8_t* d_left, const ui
         int rc = sgm_chunk(sg, m, L, R, width, height, O, s);
         if (rc) return rc;
     }
-    return RTDM_OK;
+    return sgm_overflow_check(sg, s);                  // (windows > 17 only: this call then synchronises the stream)
 }
 
 int rtdm_sgm_compute(rtdm_sgm* sg, const uint8_t* left, size_t left_pitch, const uint8_t* right, size_t right_pitch,
@@ -1118,7 +1141,7 @@ int rtdm_sgm_compute(rtdm_sgm* sg, const uint8_t* left, size_t left_pitch, const
     if (rc) return rc;
     HIPC(hipMemcpy2DAsync(disp, disp_pitch, sg->dOut, (size_t)width * 2, (size_t)width * 2, height, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
-    return RTDM_OK;
+    return sgm_overflow_check(sg, s);
 }
 
 // ---- rectification in front of the matcher (estimator.cpp:29-39) ----------------------------------------------

@@ -143,9 +143,12 @@ struct SGMBuffers {
     uint8_t* pix;            // pixel cost                 [n][H][W1][D]
     uint16_t *C, *S;         // block cost, aggregated     [n][H][W1][D]
     int32_t *label, *size, *rowcnt; uint32_t* runs; int16_t* headmap;   // speckle filter workspace
+    int32_t* ovf;            // set to 1 by the block-cost kernel where a block cost + P2 passes 32767 (windows > 17 only)
 };
+// cost_limit > 0: block costs above it set *b.ovf (the caller reads it back: rtdm_api.hip)
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
-                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream);
+                int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream,
+                int cost_limit = 0);
 
 // Depth statistics after the matcher (estimator.cpp:75-77, 206-263).  q = the 4x4 reprojection matrix Q, row major.
 struct DepthQ { double q[16]; };

@@ -3,7 +3,7 @@
  * BlockMatcher with SWSemiGlobalMatcher's constructor (include/stereo-matcher/sgbm-sw.h:27-28) plus the frame size.
  * Like SWSemiGlobalMatcher it is not selected by main.cpp unless the maintainer does so.  The device module runs
  * cv::StereoSGBM's MODE_SGBM as restated in oracle/sgm_oracle.c (bit-exact against that restatement; against the
- * library itself parity is unpinned); an even blockSize runs as the next odd one (as in the library); the window must be <= 17 at the reference's P2 = 2400.
+ * library itself parity is unpinned); an even blockSize runs as the next odd one (as in the library); with a window > 17 a frame whose block cost + P2 would pass 32767 (where the library's 16-bit costs wrap) makes compute return an error.
  */
 #ifndef INCLUDE_BM_SGBM_HIP_H_
 #define INCLUDE_BM_SGBM_HIP_H_

@@ -351,3 +351,34 @@ def test_border2_equals_border_and_the_oracle():
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-3000:]
         outs[flag] = [ln for ln in p.stdout.splitlines() if ln.startswith("CRC")]
     assert outs["1"] == outs["0"] and len(outs["1"]) == 14
+
+
+# ---- StereoSGBM: any block size (sgbm-sw.cpp:15 passes the caller's through) ---------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("bs,paths", [(19, 8), (21, 5), (4, 8), (18, 5), (25, 8)])
+def test_sgm_windows_above_17_and_even_sizes(pkg, oracle, synth, bs, paths):
+    # windows > 17 run the generic block-sum kernel with the cost check on; an even size is the next odd one (as in the library)
+    D = 32
+    L, R = synth.make_pair(synth.STREAM_SEED + 900 + bs, 150, 70, D)
+    m = pkg.HIPSemiGlobalMatcher(blockSize=bs, numOfDisparities=D, width=150, height=70, paths=paths)
+    got = m.compute(L, R)
+    m.close()
+    want = oracle.sgm_compute(L, R, numDisparities=D, blockSize=bs, paths=paths)
+    assert np.array_equal(got, want), (bs, paths, int((got != want).sum()))
+
+
+@pytest.mark.gpu
+def test_sgm_refuses_the_frame_whose_costs_would_wrap(pkg, oracle, synth):
+    # flat 255 against flat 0: every pixel cost is 63, a 25 x 25 block cost 39375 > 32767 - P2 -- the library's short
+    # arithmetic would wrap there, which neither the oracle nor the device restates: both refuse THIS FRAME, and the
+    # handle keeps working
+    D, W, H = 16, 96, 40
+    Lo, Ro = np.full((H, W), 255, np.uint8), np.zeros((H, W), np.uint8)
+    m = pkg.HIPSemiGlobalMatcher(blockSize=25, numOfDisparities=D, width=W, height=H, paths=8)
+    with pytest.raises(Exception):
+        m.compute(Lo, Ro)
+    with pytest.raises(ValueError):
+        oracle.sgm_compute(Lo, Ro, numDisparities=D, blockSize=25)
+    L, R = synth.make_pair(synth.STREAM_SEED + 77, W, H, D)
+    assert np.array_equal(m.compute(L, R), oracle.sgm_compute(L, R, numDisparities=D, blockSize=25))
+    m.close()

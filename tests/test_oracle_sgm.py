@@ -61,8 +61,7 @@ def test_kat_constant_image_picks_disparity_zero(oracle):
 
 def test_parameter_validation(oracle, synth):
     L, R = synth.make_pair(synth.STREAM_SEED, 64, 20, 16)
-    # blockSize 19: 93 * 19^2 + 2400 > 32767, where the library's 16-bit costs wrap (deviation (a) of sgm_oracle.c)
-    for bad in (dict(numDisparities=20), dict(blockSize=0), dict(uniquenessRatio=101), dict(blockSize=19), dict(blockSize=18)):
+    for bad in (dict(numDisparities=20), dict(blockSize=0), dict(uniquenessRatio=101), dict(blockSize=257)):
         kw = dict(numDisparities=16); kw.update(bad)
         with pytest.raises(ValueError):
             oracle.sgm_compute(L, R, **kw)
@@ -80,6 +79,27 @@ def test_even_block_size_is_the_next_odd_one(oracle, synth):
         a = oracle.sgm_compute(L, R, numDisparities=16, blockSize=even)
         assert np.array_equal(a, oracle.sgm_compute(L, R, numDisparities=16, blockSize=even + 1))
         assert np.array_equal(a, bf.sgm(L, R, numDisparities=16, blockSize=even))
+
+
+def overflow_pair(W=96, H=40, D=16):
+    """Every pixel pair at the maximum intensity term of the pixel cost (255 >> 2 = 63; the sampling-insensitive measure
+    needs flat images for that: any structure brings a half-way point near the other image's value)."""
+    return np.full((H, W), 255, np.uint8), np.zeros((H, W), np.uint8)
+
+
+def test_windows_above_17_run_until_a_cost_would_wrap(oracle, synth):
+    # deviation (a) of sgm_oracle.c: path cost <= block cost + P2; the library's short arithmetic wraps above 32767 and that is
+    # not restated.  Windows that can get there are no longer refused outright: the frame is, if one of its block costs does.
+    L, R = synth.make_pair(synth.STREAM_SEED + 5, 90, 44, 16)
+    for bs in (19, 21, 20):
+        a = oracle.sgm_compute(L, R, numDisparities=16, blockSize=bs)
+        assert np.array_equal(a, bf.sgm(L, R, numDisparities=16, blockSize=bs)), bs
+    Lo, Ro = overflow_pair()
+    pix, Cc, _ = oracle.sgm_stages(Lo, Ro, numDisparities=16, blockSize=25)
+    assert int(pix.max()) * 25 * 25 + 2400 > 32767                      # (the uint16 block costs themselves may have wrapped)
+    with pytest.raises(ValueError):
+        oracle.sgm_compute(Lo, Ro, numDisparities=16, blockSize=25)
+    oracle.sgm_compute(Lo, Ro, numDisparities=16, blockSize=17)        # 93 * 17^2 + 2400 < 32767: can never overflow
 
 
 def test_kat_left_right_check_cannot_be_switched_off(oracle, synth):
