@@ -1173,11 +1173,14 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
         d += disp.pitch_e; h += Ws; base += Ws;
     }
     __syncthreads();
-    const int total = min(qn, QCAP);
+#ifndef MERGE_ABL          // timing-only ablations (variant builds): 1 no unions at all, 2 marks but no unions, 3 no queue either
+#define MERGE_ABL 0
+#endif
+    const int total = MERGE_ABL == 1 || MERGE_ABL == 3 ? 0 : min(qn, QCAP);
     for (int i = threadIdx.x; i < total; i += 256) {
         const int a = queue[i].x, b = queue[i].y;
-        if (spk_large_contact(size, a, b, maxSize)) continue;
-        uf_union(label, a, b);
+        if (MERGE_ABL == 2) { spk_large_contact(size, a, b, maxSize); continue; }
+        uf_union_contact(label, size, a, b, maxSize);
     }
 }
 

@@ -36,6 +36,7 @@
 // v_cndmask, v_min3, v_cmp, shifts, v_sad_u8) 4.2-4.7; v_permlane32_swap 8.1.
 #include "rtdm_select.h"
 #include "rtdm_border.h"
+#include "rtdm_border2.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -93,7 +94,8 @@ struct RingGeom {
     int rebase;          // > 0: every `rebase` trips of the row loop the ring is rebased (P -= the oldest live prefix sum), so a
                          // strip may be as long as the frame; 0: strips are short enough for 16-bit prefix sums (ring_rows_cap)
     unsigned nborder;    // border-column workgroups in FRONT of the tile workgroups (single frames and small batches, where a
-    int bgx, bgy;        // second launch or a side stream costs more than it hides; rtdm_border.h); 0: none
+    int bgx, bgy;        // second launch or a side stream costs more than it hides); 0: none
+    int b2;              // 1: they run border2_body (rtdm_border2.h: rows in the lanes), 0: border_body (rtdm_border.h)
 };
 
 // LPP = lanes per pixel: the D disparities of a pixel are split over LPP lanes of a wave (p + h * 64/LPP, h = 0..LPP-1), and
@@ -154,9 +156,11 @@ struct RingCfg {
     // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
     static constexpr int WAVES = LPP >= 8 ? 2 : LPP == 4 ? (RING_REGS <= (MINREC ? 80 : 64) ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : (RING_REGS <= 72 && NRL <= 8) ? 4 : RING_REGS <= 112 ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
-    // border-column workgroups may ride in this kernel's grid (small launches); not in the four-wave forms, whose 128
-    // registers the border body's code would overflow
+    // border-column workgroups may ride in this kernel's grid (small launches): border2_body in every form (it needs no LDS
+    // and 52-120 VGPRs for D <= 64); border_body (configurations border2 does not cover) not in the four-wave forms, whose
+    // 128 registers its code would overflow
     static constexpr bool FUSE_BORDER = WAVES < 4;
+    static constexpr bool FUSE_BORDER2 = D <= 192;  // (border2_body<256, 4> needs 261 VGPRs: it stays a launch of its own)
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
     static constexpr bool ROW_PTRS = !(LPP == 2 && RING_REGS > 88 && RING_REGS <= 112);
@@ -253,7 +257,7 @@ __device__ __forceinline__ void ring_for_rows(std::integer_sequence<int, R...>, 
 // the tile loop of the batch form came out 1.6 % slower)
 template <int D, int WS, int LPP, bool FUSE>
 __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg,
-                                                                                   BorderGeom bg)
+                                                                                   BorderGeom bg, Border2Geom b2g)
 {
     using C = RingCfg<D, WS, LPP>;
     constexpr int NGL = C::NGL, NRL = C::NRL, W1 = C::W1, LWD = C::LWD, SLOT = C::SLOT, ITEMS = C::ITEMS, PPW = C::PPW, RPG = C::RPG;
@@ -269,7 +273,12 @@ __global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ri
         if (fi < rg.nborder) {
             // border columns: a latency-bound walk, dispatched first so that it runs under the tiles
             const unsigned per = (unsigned)(rg.bgx * rg.bgy), fr = fi / per, id = fi - fr * per;
-            border_body<(D + 63) / 64>((unsigned char*)lds, Lp, Rp, disp, cost, g, bg, (int)(id % rg.bgx), (int)(id / rg.bgx), (int)fr);
+            if (C::FUSE_BORDER2 && rg.b2) {
+                const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+                border2_body<D, C::NP>(Lp, Rp, disp, cost, g, b2g, (int)(id % rg.bgx) * 4 + wave, (int)(id / rg.bgx), (int)fr);
+            } else if constexpr (C::FUSE_BORDER) {
+                border_body<(D + 63) / 64>((unsigned char*)lds, Lp, Rp, disp, cost, g, bg, (int)(id % rg.bgx), (int)(id / rg.bgx), (int)fr);
+            }
             return;
         }
         fi -= rg.nborder;
@@ -715,12 +724,20 @@ static bool ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
     rg.chunk = xcd_local ? (rg.nitems + 7) / 8 : 0;
     const unsigned grid = rg.chunk ? rg.chunk * 8 : rg.nitems;
     BorderGeom bg{};
+    Border2Geom b2g{};
     size_t blds = 0;
-    rg.nborder = 0; rg.bgx = rg.bgy = 0;
-    if (fuse_border && C::FUSE_BORDER) {
+    rg.nborder = 0; rg.bgx = rg.bgy = 0; rg.b2 = 0;
+    bool fused = false;                               // the border columns are dealt with by this launch
+    if (fuse_border) {
         int lx0, lx1, rx0, rx1;
         fast_border_ranges(g, &lx0, &lx1, &rx0, &rx1);
-        if (border_geometry(g, lx0, lx1, rx0, rx1, n, &bg, &rg.bgx, &rg.bgy, &blds)) rg.nborder = (unsigned)(rg.bgx * rg.bgy) * (unsigned)n;
+        static const int fuse2 = env_int("RTDM_RING_FUSE_BORDER2", 1);   // A/B: 0 = border2 never rides in this grid (round 3's first form)
+        if (fuse2 && C::FUSE_BORDER2 && border2_plan(g, lx0, lx1, rx0, rx1, &b2g, &rg.bgx, &rg.bgy)) {
+            rg.b2 = 1; fused = true;
+            rg.nborder = (unsigned)(rg.bgx * rg.bgy) * (unsigned)n;
+        } else if constexpr (C::FUSE_BORDER) {
+            if (border_geometry(g, lx0, lx1, rx0, rx1, n, &bg, &rg.bgx, &rg.bgy, &blds)) { rg.nborder = (unsigned)(rg.bgx * rg.bgy) * (unsigned)n; fused = true; }
+        }
     }
     static const size_t ldspad = [] { const char* e = getenv("RTDM_RING_LDSPAD"); return e ? (size_t)atol(e) : (size_t)0; }();
     const size_t ldsb = max((size_t)4 * C::WAVE_LDS * sizeof(uint32_t), blds) + ldspad;   // (padding: occupancy experiments)
@@ -737,13 +754,11 @@ static bool ring_launch_one(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, con
                 while (g0 < want && !granted.compare_exchange_weak(g0, want, std::memory_order_release)) {}
             }
         }
-        hipLaunchKernelGGL((k_search_ring<D, WS, LPP, F>), dim3(grid + rg.nborder), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg, bg);
+        hipLaunchKernelGGL((k_search_ring<D, WS, LPP, F>), dim3(grid + rg.nborder), dim3(256), ldsb, stream, Lp, Rp, disp, (uint16_t*)cost, g, rg, bg, b2g);
     };
-    if constexpr (C::FUSE_BORDER) {
-        if (rg.nborder) { launch(std::true_type{}); return true; }
-    }
+    if (rg.nborder) { launch(std::true_type{}); return true; }
     launch(std::false_type{});
-    return false;
+    return fused;                                     // (true without border workgroups: there are no border columns)
 }
 
 bool ring_search_supported(const BMGeom& g)

@@ -92,6 +92,31 @@ __device__ __forceinline__ void uf_union(int32_t* parent, int a, int b)
     }
 }
 
+// uf_union for a contact whose two nodes are usually still roots (the speckle merge: every node starts as one), with the
+// "large run" shortcut of the speckle filter folded in -- all four first reads (both parents, both sizes) are issued
+// together.  Agent-scope accesses cost a trip to memory each (~1 us), and a merge kernel on ONE frame is nothing but such
+// chains: sizes -> find a -> find b -> hook was four trips per contact, this is two.
+// Returns without uniting if at least one run is longer than maxSize; the other one is then marked (see spk_large_contact).
+__device__ __forceinline__ void uf_union_contact(int32_t* parent, int32_t* size, int a, int b, int maxSize)
+{
+    int pa = ld_relaxed(&parent[a]), pb = ld_relaxed(&parent[b]);
+    const bool la = ld_relaxed(&size[a]) > maxSize, lb = ld_relaxed(&size[b]) > maxSize;
+    if (la || lb) {
+        if (la != lb) atomicMax(&size[la ? b : a], maxSize + 1);
+        return;
+    }
+    for (;;) {
+        // walk both up to their roots (path halving as in uf_find; pa / pb are the parents already read)
+        while (pa != a) { const int gp = ld_relaxed(&parent[pa]); if (gp == pa) { a = pa; break; } st_relaxed(&parent[a], gp); a = gp; pa = ld_relaxed(&parent[a]); }
+        while (pb != b) { const int gp = ld_relaxed(&parent[pb]); if (gp == pb) { b = pb; break; } st_relaxed(&parent[b], gp); b = gp; pb = ld_relaxed(&parent[b]); }
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; }    // a > b: hang a under b
+        const int old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        pa = old; pb = b;                                // a was no longer a root: go on from its parent; b is (was) a root
+    }
+}
+
 // Speckle "init" for one row held in LDS (d[0..W)): finds the horizontal runs, makes every run head
 // its own parent with the run length as its size, appends (x | len << 16) to the row's run list and
 // writes the per-pixel head map (x of the run head, int16) that the merge step reads.

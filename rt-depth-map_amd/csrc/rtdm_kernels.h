@@ -107,6 +107,8 @@ void launch_search_border(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const
                           hipStream_t stream, int lx0, int lx1, int rx0, int rx1);
 // second form (k_search_border2.hip): one wave = one border column x 64 rows, rows in the lanes, disparities unrolled; 4-5x
 // fewer instructions per pixel.  Returns false (nothing launched) for what it does not cover; launch_search_border tries it first.
+struct Border2Geom;
+bool border2_plan(const BMGeom& g, int lx0, int lx1, int rx0, int rx1, Border2Geom* bg, int* gx, int* gy);
 bool launch_search_border2(Plane8 Lp, Plane8 Rp, Plane16W disp, void* cost, const BMGeom& g, int n,
                            hipStream_t stream, int lx0, int lx1, int rx0, int rx1);
 
