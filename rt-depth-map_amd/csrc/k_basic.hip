@@ -906,7 +906,8 @@ int launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12M
         static const int pairs_env = [] { const int v = env_int("RTDM_LR_PAIRS", 1); return (v == 2 || v == 4 || v == 8) ? v : 1; }();
         // two rows per workgroup where the half-wave form wastes fewer lanes than the whole-wave form and fits 512 threads
         const int waves1 = (chunks + 63) / 64, waves2 = (chunks + 31) / 32;
-        const bool two = two_env && waves2 <= 8 && nrows >= 2 && waves2 < 2 * waves1;
+        static const int two_eq = env_int("RTDM_LR_TWO_EQ", 1);      // A/B: 1 = the half-wave form also where it only ties on lanes (W = 320)
+        const bool two = two_env && waves2 <= 8 && nrows >= 2 && (waves2 < 2 * waves1 || (two_eq && waves2 == 2 * waves1));
         // packed form (k_lrcheck_pk): costs below 32768, every quantity of the consistency / closeness tests inside int16,
         // LDS byte addresses inside 16 bits
         static const int pk_env = env_int("RTDM_LR_PACKED", 1);      // A/B: 0 = k_lrcheck_vec; NIT from RTDM_LR_PK_PAIRS
