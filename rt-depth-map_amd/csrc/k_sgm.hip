@@ -389,6 +389,182 @@ __global__ __launch_bounds__(256) void k_sgm_path_w(const uint16_t* C, uint16_t*
     }
 }
 
+// Half-wave form of the path pass (round 3, second half): one HALF-WAVE per path line, two neighbouring lines per wave, and
+// the whole recurrence in packed 16-bit arithmetic.  A lane holds 2 * NP2 consecutive disparities as NP2 u16 pairs
+// (D = 64 * NP2 fills the 32 lanes; a smaller D leaves the upper lanes dead), so
+//   * a step is v_pk_min/add/sub_u16 on pairs -- L_r <= block cost + P2 <= 32767 (rtdm_sgm_create) and the "no neighbour"
+//     value is 0xffff under a saturating + P1 --, d - 1 / d + 1 of a pair are two v_alignbit over (previous, own, next)
+//     pair, the pairs at the lane's ends come from the neighbouring lanes by DPP wave shifts (replaced by 0xffff at the
+//     half-wave's ends), and S is added as it was loaded: no unpacking, no packing;
+//   * the line minimum is four DPP steps inside the rows of 16 and one v_permlane16_swap between the two rows of a half, for
+//     both lines at once;
+//   * the two lines of a wave are neighbours in memory for every direction but the horizontal ones (columns x and x + 1 of
+//     one row: 2 * 2 D bytes in one piece), which halves the number of separate pieces the pass asks HBM for.
+// Same values as k_sgm_path_w / k_sgm_path (tests: every D, both modes, against the oracle).
+typedef unsigned short sgm_us2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sgm_add2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, (sgm_us2w)(__builtin_bit_cast(sgm_us2w, a) + __builtin_bit_cast(sgm_us2w, b))); }
+__device__ __forceinline__ uint32_t sgm_sub2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, (sgm_us2w)(__builtin_bit_cast(sgm_us2w, a) - __builtin_bit_cast(sgm_us2w, b))); }
+__device__ __forceinline__ uint32_t sgm_adds2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(sgm_us2w, a), __builtin_bit_cast(sgm_us2w, b))); }
+
+template <int NP2> struct PackW { uint32_t w[NP2]; };
+template <int NP2>
+__device__ __forceinline__ PackW<NP2> ld_w(const uint16_t* p)
+{
+    PackW<NP2> r;
+    if constexpr (NP2 == 1) { r.w[0] = *(const uint32_t*)p; }
+    else if constexpr (NP2 == 2) { const uint2 v = *(const uint2*)p; r.w[0] = v.x; r.w[1] = v.y; }
+    else { const uint4 v = *(const uint4*)p; r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w; }
+    return r;
+}
+template <int NP2>
+__device__ __forceinline__ void st_w(uint16_t* p, const uint32_t* o)
+{
+    if constexpr (NP2 == 1) { *(uint32_t*)p = o[0]; }
+    else if constexpr (NP2 == 2) { *(uint2*)p = make_uint2(o[0], o[1]); }
+    else { *(uint4*)p = make_uint4(o[0], o[1], o[2], o[3]); }
+}
+
+// minimum over the lane's half-wave, in every lane of that half (values < 2^31)
+__device__ __forceinline__ int half_min_i32(int v)
+{
+#define RTDM_DPP_MIN(ctrl) v = min(v, __builtin_amdgcn_update_dpp(0x7fffffff, v, ctrl, 0xf, 0xf, false))
+    RTDM_DPP_MIN(0xB1); RTDM_DPP_MIN(0x4E); RTDM_DPP_MIN(0x141); RTDM_DPP_MIN(0x140);      // the row's minimum in each of its lanes
+#undef RTDM_DPP_MIN
+    const auto s = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);   // {rows 0 0 2 2, rows 1 1 3 3}
+    return min((int)s[0], (int)s[1]);
+}
+
+template <int NP2, int PF, bool LAST>
+__global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t* S, SGMGeom g, int dx, int dy, int P1, int P2,
+                                                    int first_dir, int nlines, SgmWin* win, int uniq)
+{
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int line0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (line0 >= nlines) return;                                  // whole waves only
+    const int line = min(line0 + half, nlines - 1);
+    const bool line_ok = line0 + half < nlines;
+    const int D = g.D, W1 = g.W1, H = g.H;
+    int sx, sy;
+    if (dy == 0) { sy = line; sx = dx > 0 ? 0 : W1 - 1; }
+    else if (dx == 0) { sx = line; sy = dy > 0 ? 0 : H - 1; }
+    else if (line < W1) { sx = line; sy = dy > 0 ? 0 : H - 1; }
+    else { const int k = line - W1 + 1; sx = dx > 0 ? 0 : W1 - 1; sy = dy > 0 ? k : H - 1 - k; }
+    const int nx = dx > 0 ? W1 - sx : (dx < 0 ? sx + 1 : 0x7fffffff);
+    const int ny = dy > 0 ? H - sy : (dy < 0 ? sy + 1 : 0x7fffffff);
+    const int nsteps = line_ok ? min(nx, ny) : 0;                 // of this half's line
+    const int nmax = max(__builtin_amdgcn_readlane(nsteps, 0), __builtin_amdgcn_readlane(nsteps, 32));
+    const int d0 = hl * 2 * NP2;
+    const bool live = d0 < D;                                     // D is a multiple of 16 = of 2 * NP2
+    const uint32_t NONE = 0xffffffffu;
+    const long stride = ((long)dy * W1 + dx) * D;
+    const size_t off0 = (size_t)blockIdx.y * H * W1 * D + ((size_t)sy * W1 + sx) * D + (live ? d0 : 0);
+    const uint16_t* cp = C + off0;
+    uint16_t* sp = S + off0;
+    const uint32_t P1s = (uint32_t)P1 * 0x10001u, P2s = (uint32_t)P2 * 0x10001u;
+    PackW<NP2> cr[PF], sr[PF];
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+        if (k < nsteps) {
+            cr[k] = ld_w<NP2>(cp + (long)k * stride);
+            if (!first_dir) sr[k] = ld_w<NP2>(sp + (long)k * stride);
+        }
+    }
+    uint32_t l[NP2];
+    uint32_t mps = 0, mpP2 = 0;                                   // previous pixel's line minimum, and that + P2, in both halves
+    for (int base = 0; base < nmax; base += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; ++k) {
+            const int step = base + k;
+            if (step >= nmax) break;
+            const PackW<NP2> c = cr[k], sv = sr[k];
+            if (step + PF < nsteps) {
+                cr[k] = ld_w<NP2>(cp + (long)(step + PF) * stride);
+                if (!first_dir) sr[k] = ld_w<NP2>(sp + (long)(step + PF) * stride);
+            }
+            if (step == 0) {
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) l[r] = live ? c.w[r] : NONE;
+            } else {
+                // the pairs next to the lane's own: lane - 1's last, lane + 1's first; none outside the half-wave
+                uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)l[NP2 - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+                uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)l[0], 0x130, 0xf, 0xf, false);         // wave_shl:1
+                lo = hl == 0 ? NONE : lo;
+                hi = hl == 31 ? NONE : hi;
+                uint32_t nl[NP2];
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) {
+                    const uint32_t prev = r ? l[r - 1] : lo, next = r + 1 < NP2 ? l[r + 1] : hi;
+                    const uint32_t dn = __builtin_amdgcn_alignbit(l[r], prev, 16);      // {prev.hi, own.lo}: d - 1 of both elements
+                    const uint32_t up = __builtin_amdgcn_alignbit(next, l[r], 16);      // {own.hi, next.lo}: d + 1
+                    const uint32_t best = sgm_min2(sgm_min2(l[r], mpP2), sgm_adds2(sgm_min2(dn, up), P1s));
+                    nl[r] = sgm_sub2(sgm_add2(c.w[r], best), mps);
+                }
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) l[r] = live ? nl[r] : NONE;
+            }
+            uint32_t o[NP2];
+#pragma unroll
+            for (int r = 0; r < NP2; ++r) o[r] = first_dir ? l[r] : sgm_min2(sgm_add2(sv.w[r], l[r]), 0x7fff7fffu);   // R5
+            if constexpr (!LAST) {
+                if (live && step < nsteps) st_w<NP2>(sp + (long)step * stride, o);
+            } else {
+                // winner-take-all on the two finished pixels of the wave (as in k_sgm_path_w<.., true>, but every quantity is a
+                // per-half VECTOR value: both lines are decided by the same instructions).  None of this feeds the recurrence.
+                int v[2 * NP2];
+                unsigned key = 0x7fffffffu;
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) {
+                    v[2 * r] = (int)(o[r] & 0xffffu); v[2 * r + 1] = (int)(o[r] >> 16);
+                    key = min(key, ((unsigned)v[2 * r] << 8) | (unsigned)(d0 + 2 * r));
+                    key = min(key, ((unsigned)v[2 * r + 1] << 8) | (unsigned)(d0 + 2 * r + 1));
+                }
+                key = (unsigned)half_min_i32(live ? (int)key : 0x7fffffff);     // keys are < 2^24
+                const int mins = (int)(key >> 8), bd = (int)(key & 0xffu);
+                bool hit = false;
+                const int lim = mins * 100;
+#pragma unroll
+                for (int j = 0; j < 2 * NP2; ++j) hit |= (unsigned)(d0 + j - bd + 1) > 2u && v[j] * (100 - uniq) < lim;
+                const unsigned long long hits = __ballot(hit && live);
+                const bool rejected = (half ? (uint32_t)(hits >> 32) : (uint32_t)hits) != 0u;
+                // S[d* +- 1]: the pair that holds it, from the lane that holds it (ds_bpermute, no LDS memory involved)
+                const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
+                constexpr int LG = NP2 == 1 ? 1 : (NP2 == 2 ? 2 : 3);         // log2 of the disparities per lane
+                const int ap = ((lane & 32) + (ip >> LG)) << 2, an = ((lane & 32) + (in >> LG)) << 2;
+                uint32_t wp = 0, wn = 0;
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) {
+                    const uint32_t tp = (uint32_t)__builtin_amdgcn_ds_bpermute(ap, (int)o[r]);
+                    const uint32_t tn = (uint32_t)__builtin_amdgcn_ds_bpermute(an, (int)o[r]);
+                    if (((ip >> 1) & (NP2 - 1)) == r) wp = tp;
+                    if (((in >> 1) & (NP2 - 1)) == r) wn = tn;
+                }
+                const int s_p = (int)((wp >> ((ip & 1) << 4)) & 0xffffu), s_n = (int)((wn >> ((in & 1) << 4)) & 0xffffu);
+                int d16 = bd * 16;
+                if (bd > 0 && bd < D - 1) {
+                    const int den = max(s_n + s_p - 2 * mins, 1);
+                    d16 += div_trunc_rcp((s_n - s_p) * 16 + den, den * 2);            // |numerator| < 2^21
+                }
+                SgmWin wv;
+                wv.d16 = (int16_t)((g.minD - 1) * 16); wv.bd = (int16_t)(g.minD - 1); wv.mins = 0; wv.pad = 0;
+                if (!rejected) { wv.d16 = (int16_t)(d16 + g.minD * 16); wv.bd = (int16_t)(bd + g.minD); wv.mins = (uint16_t)mins; }
+                if (hl == 0 && step < nsteps) {
+                    const int xi = sx + step * dx, yy = sy + step * dy;
+                    win[((size_t)blockIdx.y * H + yy) * W1 + xi] = wv;
+                }
+            }
+            uint32_t mm = l[0];
+#pragma unroll
+            for (int r = 1; r < NP2; ++r) mm = sgm_min2(mm, l[r]);
+            const int m = half_min_i32((int)min(mm & 0xffffu, mm >> 16));
+            mps = (uint32_t)m * 0x10001u;
+            mpP2 = sgm_add2(mps, P2s);
+        }
+    }
+}
+
 // winner-take-all + uniqueness + sub-pixel + left-right check; one workgroup per row.  Each WAVE takes
 // every 4th pixel of the row with its LANES on the disparities (coalesced 2*D-byte reads of S): wave-min of
 // the key S << 8 | d (first minimum), __any() for the uniqueness test, readlane for S[d* +- 1].
@@ -599,6 +775,9 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     if (g.D % npl) npl = 4;
     static const int wave_paths = env_int("RTDM_SGM_WAVE_PATHS", 1);
     const bool aligned = (((size_t)b.C | (size_t)b.S) & 7) == 0;
+    const bool aligned16 = (((size_t)b.C | (size_t)b.S) & 15) == 0;
+    // RTDM_SGM_HALF=0 (A/B): every path pass on k_sgm_path_w (one wave per line, 32-bit arithmetic)
+    static const int half_paths = env_int("RTDM_SGM_HALF", 2);
     // RTDM_SGM_FUSE_SELECT=0 (A/B): the last direction writes S like the others and k_sgm_select reads it back
     static const int fuse_env = env_int("RTDM_SGM_FUSE_SELECT", 1);
     const bool fuse_select = fuse_env && wave_paths && aligned && g.D <= 256;
@@ -608,12 +787,20 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
         const int dx = dirs[k][0], dy = dirs[k][1];
         if (paths == 5 && dy < 0) continue;          // MODE_SGBM's five directions: nothing runs upwards
         const int lines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
-        if (wave_paths && aligned && g.D <= 256) {
+        const bool last = fuse_select && k == last_dir;
+        if (half_paths && wave_paths && aligned16 && g.D <= 256 && (!last || half_paths > 1)) {
+            // half-wave lines, packed arithmetic: eight lines per workgroup (RTDM_SGM_HALF=1: all passes but the last)
+            const dim3 hgrid((lines + 7) / 8, n);
+            const int first = k == 0 ? 1 : 0;
+#define RTDM_PATHH(N, P) do { if (last) hipLaunchKernelGGL((k_sgm_path_h<N, P, true>), hgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); \
+                              else hipLaunchKernelGGL((k_sgm_path_h<N, P, false>), hgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); } while (0)
+            if (g.D <= 64) RTDM_PATHH(1, 8); else if (g.D <= 128) RTDM_PATHH(2, 8); else RTDM_PATHH(4, 8);
+#undef RTDM_PATHH
+        } else if (wave_paths && aligned && g.D <= 256) {
             const dim3 wgrid((lines + 3) / 4, n);
             const int first = k == 0 ? 1 : 0;
 #define RTDM_PATHW(N, P) do { if (last) hipLaunchKernelGGL((k_sgm_path_w<N, P, true>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); \
                               else hipLaunchKernelGGL((k_sgm_path_w<N, P, false>), wgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); } while (0)
-            const bool last = fuse_select && k == last_dir;
             switch (npl) {
                 case 1: RTDM_PATHW(1, 8); break;
                 case 2: RTDM_PATHW(2, 8); break;

@@ -382,3 +382,42 @@ def test_sgm_refuses_the_frame_whose_costs_would_wrap(pkg, oracle, synth):
     L, R = synth.make_pair(synth.STREAM_SEED + 77, W, H, D)
     assert np.array_equal(m.compute(L, R), oracle.sgm_compute(L, R, numDisparities=D, blockSize=25))
     m.close()
+
+
+# ---- StereoSGBM path passes on half-waves (k_sgm_path_h): every numDisparities, both modes ----------------------------------------
+_SGM_HALF_CASES = r'''
+import sys, zlib
+sys.path.insert(0, %r)
+import importlib
+import numpy as np
+pkg = importlib.import_module("rt-depth-map_amd")
+from oracle import oracle as orc
+orc.build()
+synth = pkg.synth
+for D in range(16, 257, 16):
+    for paths, W, H in ((8, D + 61, 23), (5, D + 44, 18)):
+        L, R = synth.make_pair(synth.STREAM_SEED + 4000 + D + paths, W, H, D)
+        m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, paths=paths, P1=600 if D %% 32 else 37, P2=2400 if D %% 48 else 30000)
+        got = m.compute(L, R)
+        m.close()
+        want = orc.sgm_compute(L, R, numDisparities=D, paths=paths, P1=600 if D %% 32 else 37, P2=2400 if D %% 48 else 30000)
+        assert np.array_equal(got, want), (D, paths, int((got != want).sum()))
+        print("CRC", D, paths, zlib.crc32(got.tobytes()))
+print("ok")
+'''
+
+
+@pytest.mark.gpu
+def test_sgm_half_wave_paths_every_d_and_equal_to_the_wave_form():
+    # a lane of k_sgm_path_h holds 2 / 4 / 8 disparities (D <= 64 / 128 / 256): every multiple of 16 leaves a different number of
+    # dead lanes; W1 = 61 (odd: the last wave of a vertical pass carries one line) and 44; P2 = 30000 (packed u16 sums:
+    # minimum + P2 stays below 65536).  RTDM_SGM_HALF=0 runs the round-2 form (one wave per line, 32-bit): same bytes.
+    import subprocess, sys
+    outs = {}
+    for flag in ("2", "1", "0"):
+        env = dict(os.environ, RTDM_SGM_HALF=flag)
+        p = subprocess.run([sys.executable, "-c", _SGM_HALF_CASES % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=900, env=env)
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (flag, p.stdout[-500:], p.stderr[-3000:])
+        outs[flag] = [ln for ln in p.stdout.splitlines() if ln.startswith("CRC")]
+    assert outs["2"] == outs["0"] == outs["1"] and len(outs["2"]) == 32
