@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define RTDM_ABI_VERSION 2   /* 2: rtdm_bm_params.legacy_right_clamp, rtdm_bm_get_tuner_stats */
+#define RTDM_ABI_VERSION 3   /* 2: rtdm_bm_params.legacy_right_clamp, rtdm_bm_get_tuner_stats; 3: rtdm_sgm_get_pass_stats */
 
 typedef enum rtdm_status {
     RTDM_OK = 0,
@@ -182,6 +182,10 @@ int rtdm_sgm_compute(rtdm_sgm* sg, const uint8_t* left, size_t left_pitch, const
 int rtdm_sgm_compute_device(rtdm_sgm* sg, int n, const uint8_t* d_left, const uint8_t* d_right,
                             size_t pitch, size_t frame_stride, int width, int height,
                             int16_t* d_disp, size_t disp_pitch, size_t disp_frame_stride, void* hip_stream);
+/* How the path directions of this handle's calls have run so far: *sweeps = row-synchronous passes launched (three directions
+ * each: k_sgm_sweep), *gave_up = 1 once such a pass has given up waiting for a neighbouring strip (the call that finds this
+ * returns RTDM_ERR_HIP once; from then on the handle runs one pass per direction).  Either pointer may be NULL. */
+int rtdm_sgm_get_pass_stats(const rtdm_sgm* sg, long* sweeps, int* gave_up);
 
 /* ---- the step after the matcher, kept on the device ------------
  * rtdm_bm_compute_depth <- estimator.cpp:56 + 75-77: bm->compute(...); left_disp /= 16.;

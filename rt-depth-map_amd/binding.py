@@ -88,6 +88,7 @@ def lib():
         "rtdm_sgm_destroy": (None, [vp]),
         "rtdm_sgm_compute": (C.c_int, [vp, u8p, sz, u8p, sz, C.c_int, C.c_int, i16p, sz]),
         "rtdm_sgm_compute_device": (C.c_int, [vp, C.c_int, u8p, u8p, sz, sz, C.c_int, C.c_int, i16p, sz, sz, vp]),
+        "rtdm_sgm_get_pass_stats": (C.c_int, [vp, C.POINTER(C.c_long), C.POINTER(C.c_int)]),
         "rtdm_bm_compute_depth": (C.c_int, [vp, u8p, sz, u8p, sz, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, sz,
                                             C.POINTER(Region), C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), i16p, sz]),
         "rtdm_depth_stats_device": (C.c_int, [C.c_int, i16p, sz, C.c_int, C.c_int, C.POINTER(C.c_double), u8p, sz,
@@ -123,7 +124,7 @@ EXPORTS = ("rtdm_strerror rtdm_last_hip_error rtdm_abi_version rtdm_device_count
            "rtdm_bm_get_stage_time rtdm_bm_reset_stage_times rtdm_bm_search_variant rtdm_bm_get_tuner_stats rtdm_debug_search_kernel rtdm_morph_create "
            "rtdm_morph_destroy rtdm_morph_in_buffer rtdm_morph_out_buffer rtdm_morph_run "
            "rtdm_morph_run_device rtdm_synth_pairs_device rtdm_sgm_default_params rtdm_sgm_create rtdm_sgm_destroy "
-           "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_bm_compute_depth rtdm_depth_stats_device "
+           "rtdm_sgm_compute rtdm_sgm_compute_device rtdm_sgm_get_pass_stats rtdm_bm_compute_depth rtdm_depth_stats_device "
            "rtdm_rectify_create rtdm_rectify_destroy rtdm_rectify_gray rtdm_rectify_rgb rtdm_rectify_gray_device "
            "rtdm_bm_compute_rgb rtdm_bm_compute_rgb_device rtdm_objects_create rtdm_objects_destroy rtdm_objects_detect "
            "rtdm_estimate_frame").split()

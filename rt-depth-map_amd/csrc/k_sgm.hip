@@ -437,6 +437,52 @@ __device__ __forceinline__ int half_min_i32(int v)
     return min((int)s[0], (int)s[1]);
 }
 
+// Winner-take-all on the finished pixels of a wave's two half-waves (k_sgm_select's first half; as in k_sgm_path_w<.., true>,
+// but every quantity is a per-half VECTOR value: both pixels are decided by the same instructions).  o = the aggregated
+// costs of the lane's 2 * NP2 disparities d0 .. as u16 pairs.  Every lane of a half returns that half's record.
+template <int NP2>
+__device__ __forceinline__ SgmWin sgm_wta_half(const uint32_t* o, bool live, int lane, int d0, int D, int uniq, int minD)
+{
+    int v[2 * NP2];
+    unsigned key = 0x7fffffffu;
+#pragma unroll
+    for (int r = 0; r < NP2; ++r) {
+        v[2 * r] = (int)(o[r] & 0xffffu); v[2 * r + 1] = (int)(o[r] >> 16);
+        key = min(key, ((unsigned)v[2 * r] << 8) | (unsigned)(d0 + 2 * r));
+        key = min(key, ((unsigned)v[2 * r + 1] << 8) | (unsigned)(d0 + 2 * r + 1));
+    }
+    key = (unsigned)half_min_i32(live ? (int)key : 0x7fffffff);     // keys are < 2^24
+    const int mins = (int)(key >> 8), bd = (int)(key & 0xffu);
+    bool hit = false;
+    const int lim = mins * 100;
+#pragma unroll
+    for (int j = 0; j < 2 * NP2; ++j) hit |= (unsigned)(d0 + j - bd + 1) > 2u && v[j] * (100 - uniq) < lim;
+    const unsigned long long hits = __ballot(hit && live);
+    const bool rejected = ((lane & 32) ? (uint32_t)(hits >> 32) : (uint32_t)hits) != 0u;
+    // S[d* +- 1]: the pair that holds it, from the lane that holds it (ds_bpermute, no LDS memory involved)
+    const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
+    constexpr int LG = NP2 == 1 ? 1 : (NP2 == 2 ? 2 : 3);         // log2 of the disparities per lane
+    const int ap = ((lane & 32) + (ip >> LG)) << 2, an = ((lane & 32) + (in >> LG)) << 2;
+    uint32_t wp = 0, wn = 0;
+#pragma unroll
+    for (int r = 0; r < NP2; ++r) {
+        const uint32_t tp = (uint32_t)__builtin_amdgcn_ds_bpermute(ap, (int)o[r]);
+        const uint32_t tn = (uint32_t)__builtin_amdgcn_ds_bpermute(an, (int)o[r]);
+        if (((ip >> 1) & (NP2 - 1)) == r) wp = tp;
+        if (((in >> 1) & (NP2 - 1)) == r) wn = tn;
+    }
+    const int s_p = (int)((wp >> ((ip & 1) << 4)) & 0xffffu), s_n = (int)((wn >> ((in & 1) << 4)) & 0xffffu);
+    int d16 = bd * 16;
+    if (bd > 0 && bd < D - 1) {
+        const int den = max(s_n + s_p - 2 * mins, 1);
+        d16 += div_trunc_rcp((s_n - s_p) * 16 + den, den * 2);            // |numerator| < 2^21
+    }
+    SgmWin wv;
+    wv.d16 = (int16_t)((minD - 1) * 16); wv.bd = (int16_t)(minD - 1); wv.mins = 0; wv.pad = 0;
+    if (!rejected) { wv.d16 = (int16_t)(d16 + minD * 16); wv.bd = (int16_t)(bd + minD); wv.mins = (uint16_t)mins; }
+    return wv;
+}
+
 template <int NP2, int PF, bool LAST>
 __global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t* S, SGMGeom g, int dx, int dy, int P1, int P2,
                                                     int first_dir, int nlines, SgmWin* win, int uniq)
@@ -511,45 +557,7 @@ __global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t*
             if constexpr (!LAST) {
                 if (live && step < nsteps) st_w<NP2>(sp + (long)step * stride, o);
             } else {
-                // winner-take-all on the two finished pixels of the wave (as in k_sgm_path_w<.., true>, but every quantity is a
-                // per-half VECTOR value: both lines are decided by the same instructions).  None of this feeds the recurrence.
-                int v[2 * NP2];
-                unsigned key = 0x7fffffffu;
-#pragma unroll
-                for (int r = 0; r < NP2; ++r) {
-                    v[2 * r] = (int)(o[r] & 0xffffu); v[2 * r + 1] = (int)(o[r] >> 16);
-                    key = min(key, ((unsigned)v[2 * r] << 8) | (unsigned)(d0 + 2 * r));
-                    key = min(key, ((unsigned)v[2 * r + 1] << 8) | (unsigned)(d0 + 2 * r + 1));
-                }
-                key = (unsigned)half_min_i32(live ? (int)key : 0x7fffffff);     // keys are < 2^24
-                const int mins = (int)(key >> 8), bd = (int)(key & 0xffu);
-                bool hit = false;
-                const int lim = mins * 100;
-#pragma unroll
-                for (int j = 0; j < 2 * NP2; ++j) hit |= (unsigned)(d0 + j - bd + 1) > 2u && v[j] * (100 - uniq) < lim;
-                const unsigned long long hits = __ballot(hit && live);
-                const bool rejected = (half ? (uint32_t)(hits >> 32) : (uint32_t)hits) != 0u;
-                // S[d* +- 1]: the pair that holds it, from the lane that holds it (ds_bpermute, no LDS memory involved)
-                const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
-                constexpr int LG = NP2 == 1 ? 1 : (NP2 == 2 ? 2 : 3);         // log2 of the disparities per lane
-                const int ap = ((lane & 32) + (ip >> LG)) << 2, an = ((lane & 32) + (in >> LG)) << 2;
-                uint32_t wp = 0, wn = 0;
-#pragma unroll
-                for (int r = 0; r < NP2; ++r) {
-                    const uint32_t tp = (uint32_t)__builtin_amdgcn_ds_bpermute(ap, (int)o[r]);
-                    const uint32_t tn = (uint32_t)__builtin_amdgcn_ds_bpermute(an, (int)o[r]);
-                    if (((ip >> 1) & (NP2 - 1)) == r) wp = tp;
-                    if (((in >> 1) & (NP2 - 1)) == r) wn = tn;
-                }
-                const int s_p = (int)((wp >> ((ip & 1) << 4)) & 0xffffu), s_n = (int)((wn >> ((in & 1) << 4)) & 0xffffu);
-                int d16 = bd * 16;
-                if (bd > 0 && bd < D - 1) {
-                    const int den = max(s_n + s_p - 2 * mins, 1);
-                    d16 += div_trunc_rcp((s_n - s_p) * 16 + den, den * 2);            // |numerator| < 2^21
-                }
-                SgmWin wv;
-                wv.d16 = (int16_t)((g.minD - 1) * 16); wv.bd = (int16_t)(g.minD - 1); wv.mins = 0; wv.pad = 0;
-                if (!rejected) { wv.d16 = (int16_t)(d16 + g.minD * 16); wv.bd = (int16_t)(bd + g.minD); wv.mins = (uint16_t)mins; }
+                const SgmWin wv = sgm_wta_half<NP2>(o, live, lane, d0, D, uniq, g.minD);
                 if (hl == 0 && step < nsteps) {
                     const int xi = sx + step * dx, yy = sy + step * dy;
                     win[((size_t)blockIdx.y * H + yy) * W1 + xi] = wv;
@@ -561,6 +569,192 @@ __global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t*
             const int m = half_min_i32((int)min(mm & 0xffffu, mm >> 16));
             mps = (uint32_t)m * 0x10001u;
             mpP2 = sgm_add2(mps, P2s);
+        }
+    }
+}
+
+// Row-synchronous sweep (round 3): the three directions that advance one row per step -- (0, dy), (+1, dy), (-1, dy) -- in ONE
+// pass, so C is read once and S read-modified-written once for the three of them (separate passes: three reads of C, three
+// read-modify-writes of S; with the last sweep deciding the winners, S is not written at all).  A workgroup owns a strip of
+// 8 * CPH columns of one frame and walks its rows; a half-wave owns CPH (4 or 2) neighbouring columns and keeps the previous
+// row's L_r of its 3 * CPH (column, direction) lines in registers.  A diagonal line changes column every row: inside a half-wave that is a
+// register rename (the columns are processed in the order that makes the update in-place), between the half-waves of a
+// workgroup the edge line goes through LDS (double-buffered, one barrier per row), and between neighbouring STRIPS through a
+// small ring in global memory whose 64-bit words carry their own tag (epoch << 16 | row + 1 in the high half, the u16 pair in
+// the low half: single-copy atomic, so a word that shows the expected tag is the expected data -- no fence, no L2 write-back).
+// Every strip needs its neighbours' edge of the PREVIOUS row, which they publish at the start of that row: the strips of a
+// frame advance in lockstep within a row of each other, and a wait is normally already satisfied.  All workgroups of the
+// launch must be resident at once (cooperative launch, grid <= what the device holds; launch_sgm checks); as a second line of
+// defence a wait gives up after ~1 s, sets *abortf and the pass runs to its end without waiting (the host then reports the
+// call as failed and the handle falls back to one pass per direction).
+static constexpr int SWEEP_RING = 4;                      // rows of edge data kept per (strip, side)
+__device__ __forceinline__ unsigned long long ld_u64_relaxed(const unsigned long long* p)
+{ return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_u64_relaxed(unsigned long long* p, unsigned long long v)
+{ __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// one step of one line for both half-waves of the wave: L <- C + min(Lp[d], Lp[d -+ 1] + P1, min Lp + P2) - min Lp, or C where
+// the line starts; mps <- the new line minimum in both halves of a dword.  L may alias Lp.
+template <int NP2, bool MAY_START>
+__device__ __forceinline__ void sgm_line_step(uint32_t* L, uint32_t& mps, const uint32_t* Lp, uint32_t mpsp, const uint32_t* c,
+                                              bool start, bool live, int hl, uint32_t P1s, uint32_t P2s)
+{
+    const uint32_t NONE = 0xffffffffu;
+    uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)Lp[NP2 - 1], 0x138, 0xf, 0xf, false);   // wave_shr:1
+    uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)NONE, (int)Lp[0], 0x130, 0xf, 0xf, false);         // wave_shl:1
+    lo = hl == 0 ? NONE : lo;
+    hi = hl == 31 ? NONE : hi;
+    const uint32_t mpP2 = sgm_add2(mpsp, P2s);
+    uint32_t nl[NP2];
+#pragma unroll
+    for (int r = 0; r < NP2; ++r) {
+        const uint32_t prev = r ? Lp[r - 1] : lo, next = r + 1 < NP2 ? Lp[r + 1] : hi;
+        const uint32_t dn = __builtin_amdgcn_alignbit(Lp[r], prev, 16), up = __builtin_amdgcn_alignbit(next, Lp[r], 16);
+        const uint32_t best = sgm_min2(sgm_min2(Lp[r], mpP2), sgm_adds2(sgm_min2(dn, up), P1s));
+        nl[r] = sgm_sub2(sgm_add2(c[r], best), mpsp);
+        if (MAY_START) nl[r] = start ? c[r] : nl[r];
+    }
+    uint32_t mm = NONE;
+#pragma unroll
+    for (int r = 0; r < NP2; ++r) { L[r] = live ? nl[r] : NONE; mm = sgm_min2(mm, L[r]); }
+    mps = (uint32_t)half_min_i32((int)min(mm & 0xffffu, mm >> 16)) * 0x10001u;
+}
+
+template <int NP2, bool LAST, int CPH>
+__global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* S, SGMGeom g, int dy, int P1, int P2, int strips,
+                                                   int items, unsigned long long* ring, int32_t* abortf, uint32_t epoch, SgmWin* win,
+                                                   int uniq)
+{
+    __shared__ uint32_t xch[2][8][2][NP2 + 1][32];             // [row parity][half-wave][0: (+1, dy) edge, 1: (-1, dy) edge][pairs, minimum][lane]
+    const int lane = threadIdx.x & 63, hl = lane & 31, hw = threadIdx.x >> 5;
+    const int D = g.D, W1 = g.W1, H = g.H;
+    const int d0 = hl * 2 * NP2;
+    const bool live = d0 < D;
+    const uint32_t NONE = 0xffffffffu;
+    const uint32_t P1s = (uint32_t)P1 * 0x10001u, P2s = (uint32_t)P2 * 0x10001u;
+    const size_t rowstride = (size_t)W1 * D;                   // elements
+    bool gave_up = false;                                      // (per lane; only the polling lanes ever set it)
+    for (int item = blockIdx.x; item < items; item += gridDim.x) {
+        const int f = item / strips, s = item - f * strips;
+        const int xb = s * (8 * CPH) + hw * CPH;               // the half-wave's first column
+        int xc[CPH]; bool okc[CPH];
+#pragma unroll
+        for (int c = 0; c < CPH; ++c) { okc[c] = xb + c < W1; xc[c] = min(xb + c, W1 - 1); }
+        const size_t fbase = (size_t)f * H * rowstride + (live ? d0 : 0);
+        const bool has_left = s > 0, has_right = (s + 1) * (8 * CPH) < W1;
+        unsigned long long* ring_me = ring + (size_t)(f * strips + s) * 2 * SWEEP_RING * 32 * NP2;
+        const unsigned long long* ring_l = ring_me - (size_t)2 * SWEEP_RING * 32 * NP2;                                  // strip s - 1, side 0
+        const unsigned long long* ring_r = ring_me + (size_t)2 * SWEEP_RING * 32 * NP2 + (size_t)SWEEP_RING * 32 * NP2;  // strip s + 1, side 1
+        uint32_t L0[CPH][NP2], L1[CPH][NP2], L2[CPH][NP2], m0[CPH], m1[CPH], m2[CPH];
+#pragma unroll
+        for (int c = 0; c < CPH; ++c) { m0[c] = m1[c] = m2[c] = 0; for (int r = 0; r < NP2; ++r) L0[c][r] = L1[c][r] = L2[c][r] = NONE; }
+        // this row's and the next row's costs: C and S of the half-wave's four columns, requested a row ahead
+        PackW<NP2> cn[CPH], sn[CPH];
+        {
+            const int y = dy > 0 ? 0 : H - 1;
+#pragma unroll
+            for (int c = 0; c < CPH; ++c) {
+                cn[c] = ld_w<NP2>(C + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);
+                sn[c] = ld_w<NP2>(S + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);
+            }
+        }
+        for (int t = 0; t < H; ++t) {
+            const int y = dy > 0 ? t : H - 1 - t, par = t & 1;
+            PackW<NP2> cc[CPH], sc[CPH];
+#pragma unroll
+            for (int c = 0; c < CPH; ++c) { cc[c] = cn[c]; sc[c] = sn[c]; }
+            if (t + 1 < H) {
+                const int yn = y + dy;
+#pragma unroll
+                for (int c = 0; c < CPH; ++c) {
+                    cn[c] = ld_w<NP2>(C + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
+                    sn[c] = ld_w<NP2>(S + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
+                }
+            }
+            const bool first_row = t == 0;
+            uint32_t acc[CPH][NP2];
+            const auto add_to = [&](int c, const uint32_t* L) {
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) acc[c][r] = sgm_min2(sgm_add2(acc[c][r], L[r]), 0x7fff7fffu);   // R5
+            };
+#pragma unroll
+            for (int c = 0; c < CPH; ++c) for (int r = 0; r < NP2; ++r) acc[c][r] = sc[c].w[r];
+            // (+1, dy): columns CPH - 1 ... 1 take the line of their left neighbour's previous row -- in place in that order
+#pragma unroll
+            for (int c = CPH - 1; c >= 1; --c) { sgm_line_step<NP2, true>(L1[c], m1[c], L1[c - 1], m1[c - 1], cc[c].w, first_row, live, hl, P1s, P2s); add_to(c, L1[c]); }
+            // (-1, dy): columns 0 ... CPH - 2 take their right neighbour's; a line starts at the frame's last column
+#pragma unroll
+            for (int c = 0; c <= CPH - 2; ++c) { sgm_line_step<NP2, true>(L2[c], m2[c], L2[c + 1], m2[c + 1], cc[c].w, first_row || xb + c == W1 - 1, live, hl, P1s, P2s); add_to(c, L2[c]); }
+            // the edges the neighbours will want for their next row: LDS inside the workgroup, the tagged ring between strips
+#pragma unroll
+            for (int r = 0; r < NP2; ++r) { xch[par][hw][0][r][hl] = L1[CPH - 1][r]; xch[par][hw][1][r][hl] = L2[0][r]; }
+            xch[par][hw][0][NP2][hl] = m1[CPH - 1]; xch[par][hw][1][NP2][hl] = m2[0];
+            const unsigned long long tag = ((unsigned long long)((epoch << 16) | (uint32_t)(t + 1))) << 32;
+            if (hw == 7 && has_right) {
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) st_u64_relaxed(ring_me + ((size_t)(t & (SWEEP_RING - 1)) * 32 + hl) * NP2 + r, tag | L1[CPH - 1][r]);
+            }
+            if (hw == 0 && has_left) {
+#pragma unroll
+                for (int r = 0; r < NP2; ++r)
+                    st_u64_relaxed(ring_me + (size_t)SWEEP_RING * 32 * NP2 + ((size_t)(t & (SWEEP_RING - 1)) * 32 + hl) * NP2 + r, tag | L2[0][r]);
+            }
+            // (0, dy)
+#pragma unroll
+            for (int c = 0; c < CPH; ++c) { sgm_line_step<NP2, true>(L0[c], m0[c], L0[c], m0[c], cc[c].w, first_row, live, hl, P1s, P2s); add_to(c, L0[c]); }
+            // the two lines that enter the half-wave's columns from outside
+            uint32_t inL[NP2], inR[NP2], inLm = 0, inRm = 0;
+#pragma unroll
+            for (int r = 0; r < NP2; ++r) { inL[r] = NONE; inR[r] = NONE; }
+            if (!first_row) {
+                if (hw > 0) { for (int r = 0; r < NP2; ++r) inL[r] = xch[par ^ 1][hw - 1][0][r][hl]; inLm = xch[par ^ 1][hw - 1][0][NP2][hl]; }
+                if (hw < 7) { for (int r = 0; r < NP2; ++r) inR[r] = xch[par ^ 1][hw + 1][1][r][hl]; inRm = xch[par ^ 1][hw + 1][1][NP2][hl]; }
+                const int wv = threadIdx.x >> 6;
+                if ((wv == 0 && has_left) || (wv == 3 && has_right)) {                 // wave-uniform
+                    const bool poll_l = hw == 0 && has_left, poll_r = hw == 7 && has_right;
+                    const unsigned long long* src = (poll_l ? ring_l : ring_r) + ((size_t)((t - 1) & (SWEEP_RING - 1)) * 32 + hl) * NP2;
+                    const uint32_t want = (epoch << 16) | (uint32_t)t;                  // the previous row's tag
+                    unsigned long long w[NP2];
+                    bool done = !(poll_l || poll_r) || gave_up;
+                    for (int spin = 0;; ++spin) {
+                        if (!done) {
+                            bool all = true;
+#pragma unroll
+                            for (int r = 0; r < NP2; ++r) { w[r] = ld_u64_relaxed(src + r); all &= (uint32_t)(w[r] >> 32) == want; }
+                            done = all;
+                        }
+                        if (__all(done)) break;
+                        if ((spin & 63) == 63 && (spin > (1 << 20) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                            if (!done) { gave_up = true; __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    if (poll_l) { for (int r = 0; r < NP2; ++r) inL[r] = (uint32_t)w[r]; }
+                    if (poll_r) { for (int r = 0; r < NP2; ++r) inR[r] = (uint32_t)w[r]; }
+                    // the minimum of a line that came through the ring is not sent along: take it here (both halves do, one needs it)
+                    uint32_t mmL = NONE, mmR = NONE;
+#pragma unroll
+                    for (int r = 0; r < NP2; ++r) { mmL = sgm_min2(mmL, live ? inL[r] : NONE); mmR = sgm_min2(mmR, live ? inR[r] : NONE); }
+                    const uint32_t hmL = (uint32_t)half_min_i32((int)min(mmL & 0xffffu, mmL >> 16)) * 0x10001u;
+                    const uint32_t hmR = (uint32_t)half_min_i32((int)min(mmR & 0xffffu, mmR >> 16)) * 0x10001u;
+                    if (poll_l) inLm = hmL;
+                    if (poll_r) inRm = hmR;
+                }
+            }
+            sgm_line_step<NP2, true>(L1[0], m1[0], inL, inLm, cc[0].w, first_row || xb == 0, live, hl, P1s, P2s); add_to(0, L1[0]);
+            sgm_line_step<NP2, true>(L2[CPH - 1], m2[CPH - 1], inR, inRm, cc[CPH - 1].w, first_row || xb + CPH - 1 >= W1 - 1, live, hl, P1s, P2s); add_to(CPH - 1, L2[CPH - 1]);
+            // S (or the winners)
+#pragma unroll
+            for (int c = 0; c < CPH; ++c) {
+                if constexpr (!LAST) {
+                    if (live && okc[c]) st_w<NP2>(S + fbase + (size_t)y * rowstride + (size_t)xc[c] * D, acc[c]);
+                } else {
+                    const SgmWin wv = sgm_wta_half<NP2>(acc[c], live, lane, d0, D, uniq, g.minD);
+                    if (hl == 0 && okc[c]) win[((size_t)f * H + y) * W1 + xc[c]] = wv;
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -751,6 +945,68 @@ static void launch_select(int nch, dim3 grid, size_t lds, hipStream_t stream, co
 #undef RTDM_SEL
 }
 
+static inline int sgm_np2(int D) { return D <= 64 ? 1 : (D <= 128 ? 2 : 4); }
+size_t sgm_ring_words(int maxW, int D, int max_batch)                  // sized for the narrow strips (16 columns)
+{ return (size_t)max_batch * ((size_t)(maxW + 15) / 16) * 2 * SWEEP_RING * 32 * sgm_np2(D); }
+
+// One row-synchronous pass over (0, dy), (+1, dy), (-1, dy).  false = not launched (the caller runs the three passes).
+template <int NP2, bool LAST, int CPH>
+static int sweep_capacity(const SGMBuffers& b)
+{
+    int& cap = b.sweep_cap[((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 2 + (CPH == 4 ? 1 : 0)];
+    if (cap == 0) {
+        int dev = 0, coop = 0, cus = 0, per_cu = 0;
+        cap = -1;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop &&
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sgm_sweep<NP2, LAST, CPH>, 256, 0) == hipSuccess && per_cu > 0)
+            cap = per_cu * cus;
+        (void)hipGetLastError();
+    }
+    return cap;
+}
+template <int NP2, bool LAST, int CPH>
+static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
+{
+    const int cap = sweep_capacity<NP2, LAST, CPH>(b);
+    const int strips = (g.W1 + 8 * CPH - 1) / (8 * CPH);
+    if (cap < strips) return false;
+    int items = n * strips;
+    if ((size_t)items * 2 * SWEEP_RING * 32 * NP2 > b.ring_words) return false;
+    const int grid = items <= cap ? items : cap / strips * strips;       // the strips of a frame run in the same round
+    const uint32_t epoch = (*b.epoch + 1) & 0xffffu;
+    const uint16_t* C = b.C; uint16_t* S = b.S; SGMGeom gg = g; int dyv = dy, p1 = P1, p2 = P2, st = strips, it = items, uq = uniq;
+    unsigned long long* ring = b.ring; int32_t* ab = b.abortf; uint32_t ep = epoch; SgmWin* w = win;
+    void* args[] = {&C, &S, &gg, &dyv, &p1, &p2, &st, &it, &ring, &ab, &ep, &w, &uq};
+    const hipError_t e = hipLaunchCooperativeKernel((const void*)k_sgm_sweep<NP2, LAST, CPH>, dim3(grid), dim3(256), args, 0, stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); b.sweep_cap[((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 2 + (CPH == 4 ? 1 : 0)] = -1; return false; }
+    ++*b.epoch;
+    return true;
+}
+template <int NP2, bool LAST>
+static bool launch_sweep_t(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
+{
+    // strips of 16 columns (two per half-wave) while their workgroups all fit the device at once: twice the workgroups, and a
+    // frame's rows are a serial chain -- the pass is latency bound until every SIMD holds several waves; 32 columns beyond that
+    // (RTDM_SGM_SWEEP_COLS=2 / 4 fixes the choice: A/B)
+    static const int cols_env = env_int("RTDM_SGM_SWEEP_COLS", 0);
+    const int cap2 = sweep_capacity<NP2, LAST, 2>(b);
+    const bool narrow = cols_env ? cols_env == 2 : n * ((g.W1 + 15) / 16) <= cap2;
+    if (narrow && launch_sweep_c<NP2, LAST, 2>(g, b, dy, P1, P2, n, win, uniq, stream)) return true;
+    return launch_sweep_c<NP2, LAST, 4>(g, b, dy, P1, P2, n, win, uniq, stream);
+}
+static bool launch_sweep(bool last, const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
+{
+    switch (sgm_np2(g.D) * 2 + (last ? 1 : 0)) {
+        case 2: return launch_sweep_t<1, false>(g, b, dy, P1, P2, n, win, uniq, stream);
+        case 3: return launch_sweep_t<1, true>(g, b, dy, P1, P2, n, win, uniq, stream);
+        case 4: return launch_sweep_t<2, false>(g, b, dy, P1, P2, n, win, uniq, stream);
+        case 5: return launch_sweep_t<2, true>(g, b, dy, P1, P2, n, win, uniq, stream);
+        case 8: return launch_sweep_t<4, false>(g, b, dy, P1, P2, n, win, uniq, stream);
+        default: return launch_sweep_t<4, true>(g, b, dy, P1, P2, n, win, uniq, stream);
+    }
+}
+
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
                 int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream,
                 int cost_limit)
@@ -783,9 +1039,23 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     const bool fuse_select = fuse_env && wave_paths && aligned && g.D <= 256;
     const int last_dir = paths == 5 ? 5 : 7;
     SgmWin* win = (SgmWin*)b.gr;                     // the right image's bounds are dead once the pixel costs exist: 8 bytes per pixel
+    // RTDM_SGM_SWEEP=0 (A/B): one pass per direction for the six that advance a row per step as well
+    static const int sweep_env = env_int("RTDM_SGM_SWEEP", 1);
+    bool sweep = sweep_env && half_paths && wave_paths && aligned16 && fuse_select && b.ring && b.abortf && *b.abortf == 0;
+    bool swept_down = false, swept_up = false;
     for (int k = 0; k < 8; ++k) {
         const int dx = dirs[k][0], dy = dirs[k][1];
         if (paths == 5 && dy < 0) continue;          // MODE_SGBM's five directions: nothing runs upwards
+        if (dy != 0) {
+            // (0, dy), (+1, dy), (-1, dy) in one row-synchronous pass: -> <- down [up]; the last sweep decides the winners
+            bool& done = dy > 0 ? swept_down : swept_up;
+            if (done) continue;
+            if (sweep && (k == 2 || k == 3)) {
+                const bool last_sweep = paths == 5 || dy < 0;
+                if (launch_sweep(last_sweep, g, b, dy, P1, P2, n, win, uniq, stream)) { done = true; continue; }
+                sweep = false;                       // not launched: this and the remaining directions run as passes of their own
+            }
+        }
         const int lines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
         const bool last = fuse_select && k == last_dir;
         if (half_paths && wave_paths && aligned16 && g.D <= 256 && (!last || half_paths > 1)) {

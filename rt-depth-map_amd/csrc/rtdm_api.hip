@@ -1006,7 +1006,21 @@ struct rtdm_sgm {
     SGMBuffers b;
     int cost_limit;                // > 0 (windows > 17 at P2 = 2400): a block cost above it would wrap the library's 16-bit path costs
     int32_t* hOvf;                 // page-locked copy of b.ovf
+    uint32_t sweep_epoch;          // launches of k_sgm_sweep (tags of its edge ring)
+    int sweep_cap[12];             // workgroups the device holds at once, per instantiation (0 = not asked yet)
+    bool sweep_reported;           // a give-up of the sweep has been returned to the caller
 };
+
+// The row-synchronous sweep waits on its neighbours with a bound; a pass that gave up has produced garbage and has said so in a
+// page-locked flag.  The call that finds the flag returns an error ONCE; from then on the handle runs one pass per direction.
+static int sgm_sweep_check(rtdm_sgm* sg)
+{
+    if (!sg->b.abortf || !*sg->b.abortf || sg->sweep_reported) return RTDM_OK;
+    sg->sweep_reported = true;
+    g_hip_err = "StereoSGBM: a row-synchronous sweep gave up waiting for a neighbouring strip; the output of that call is invalid "
+                "(this handle runs one pass per direction from now on)";
+    return RTDM_ERR_HIP;
+}
 
 // windows whose block cost + P2 can pass 32767: the frame is refused if it does (what is not restated is the wrap-around)
 static int sgm_overflow_check(rtdm_sgm* sg, hipStream_t s)
@@ -1069,6 +1083,12 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     if (e == hipSuccess) e = hipMalloc((void**)&sg->b.ovf, sizeof(int32_t));
     if (e == hipSuccess) e = hipMemset(sg->b.ovf, 0, sizeof(int32_t));
     if (e == hipSuccess) e = hipHostMalloc((void**)&sg->hOvf, sizeof(int32_t), hipHostMallocDefault);
+    sg->b.ring_words = sgm_ring_words(max_width, p.numDisparities, max_batch);
+    if (e == hipSuccess) e = hipMalloc((void**)&sg->b.ring, sg->b.ring_words * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(sg->b.ring, 0, sg->b.ring_words * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&sg->b.abortf, sizeof(int32_t), hipHostMallocMapped);
+    if (e == hipSuccess) *sg->b.abortf = 0;
+    sg->b.epoch = &sg->sweep_epoch; sg->b.sweep_cap = sg->sweep_cap;
     if (e != hipSuccess) {
         g_hip_err = std::string("rtdm_sgm_create: ") + hipGetErrorString(e);
         rtdm_sgm_destroy(sg);
@@ -1087,6 +1107,8 @@ void rtdm_sgm_destroy(rtdm_sgm* sg)
                     sg->b.runs, sg->b.rowcnt, sg->b.headmap};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (sg->b.ovf) (void)hipFree(sg->b.ovf);
+    if (sg->b.ring) (void)hipFree(sg->b.ring);
+    if (sg->b.abortf) (void)hipHostFree(sg->b.abortf);
     if (sg->hOvf) (void)hipHostFree(sg->hOvf);
     if (sg->stream) (void)hipStreamDestroy(sg->stream);
     delete sg;
@@ -1122,7 +1144,8 @@ int rtdm_sgm_compute_device(rtdm_sgm* sg, int n, const uint8_t* d_left, const ui
         int rc = sgm_chunk(sg, m, L, R, width, height, O, s);
         if (rc) return rc;
     }
-    return sgm_overflow_check(sg, s);                  // (windows > 17 only: this call then synchronises the stream)
+    int rc = sgm_overflow_check(sg, s);                // (windows > 17 only: this call then synchronises the stream)
+    return rc ? rc : sgm_sweep_check(sg);              // (asynchronous call: a give-up of this call's sweep shows in the next call)
 }
 
 int rtdm_sgm_compute(rtdm_sgm* sg, const uint8_t* left, size_t left_pitch, const uint8_t* right, size_t right_pitch,
@@ -1141,7 +1164,16 @@ int rtdm_sgm_compute(rtdm_sgm* sg, const uint8_t* left, size_t left_pitch, const
     if (rc) return rc;
     HIPC(hipMemcpy2DAsync(disp, disp_pitch, sg->dOut, (size_t)width * 2, (size_t)width * 2, height, hipMemcpyDeviceToHost, s));
     HIPC(hipStreamSynchronize(s));
-    return sgm_overflow_check(sg, s);
+    rc = sgm_overflow_check(sg, s);
+    return rc ? rc : sgm_sweep_check(sg);
+}
+
+int rtdm_sgm_get_pass_stats(const rtdm_sgm* sg, long* sweeps, int* gave_up)
+{
+    if (!sg) return RTDM_ERR_NULL;
+    if (sweeps) *sweeps = (long)sg->sweep_epoch;
+    if (gave_up) *gave_up = sg->b.abortf && *sg->b.abortf ? 1 : 0;
+    return RTDM_OK;
 }
 
 // ---- rectification in front of the matcher (estimator.cpp:29-39) ----------------------------------------------

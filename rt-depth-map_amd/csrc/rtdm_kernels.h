@@ -146,7 +146,13 @@ struct SGMBuffers {
     uint16_t *C, *S;         // block cost, aggregated     [n][H][W1][D]
     int32_t *label, *size, *rowcnt; uint32_t* runs; int16_t* headmap;   // speckle filter workspace
     int32_t* ovf;            // set to 1 by the block-cost kernel where a block cost + P2 passes 32767 (windows > 17 only)
+    // row-synchronous sweep (k_sgm_sweep): edge ring between neighbouring strips, give-up flag (page-locked, host readable),
+    // the handle's launch counter (tags of the ring words), how many workgroups the device holds at once per instantiation
+    unsigned long long* ring; size_t ring_words;
+    int32_t* abortf; uint32_t* epoch;
+    int* sweep_cap;          // [12], 0 = not asked yet, < 0 = unusable
 };
+size_t sgm_ring_words(int maxW, int D, int max_batch);
 // cost_limit > 0: block costs above it set *b.ovf (the caller reads it back: rtdm_api.hip)
 void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBuffers& b, int blockSize, int P1, int P2,
                 int uniq, int disp12MaxDiff, int speckleWindowSize, int speckleRange, int paths, int n, hipStream_t stream,

@@ -173,6 +173,12 @@ class HIPSemiGlobalMatcher:
                                          right.strides[0], W, H, disp.ctypes.data, W * 2), "rtdm_sgm_compute")
         return disp
 
+    def pass_stats(self):
+        """(row-synchronous sweeps launched so far, whether one has given up) -- rtdm_sgm_get_pass_stats"""
+        sw, gu = C.c_long(0), C.c_int(0)
+        B.check(B.lib().rtdm_sgm_get_pass_stats(self._h, C.byref(sw), C.byref(gu)), "rtdm_sgm_get_pass_stats")
+        return sw.value, bool(gu.value)
+
     def compute_device(self, d_left, d_right, d_disp, stream=None):
         n, H, W = d_left.shape
         B.check(B.lib().rtdm_sgm_compute_device(self._h, n, d_left.data_ptr(), d_right.data_ptr(), W, W * H, W, H,

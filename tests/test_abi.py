@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_strerror():
     B = load("binding")
     L = B.lib()
-    assert L.rtdm_abi_version() == 2
+    assert L.rtdm_abi_version() == 3
     assert L.rtdm_strerror(0) == b"ok"
     assert b"no CPU fallback" in L.rtdm_strerror(-3)
     p = B.BMParams()

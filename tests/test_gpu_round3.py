@@ -399,10 +399,12 @@ for D in range(16, 257, 16):
         L, R = synth.make_pair(synth.STREAM_SEED + 4000 + D + paths, W, H, D)
         m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, paths=paths, P1=600 if D %% 32 else 37, P2=2400 if D %% 48 else 30000)
         got = m.compute(L, R)
+        sw = m.pass_stats()[0]
         m.close()
         want = orc.sgm_compute(L, R, numDisparities=D, paths=paths, P1=600 if D %% 32 else 37, P2=2400 if D %% 48 else 30000)
         assert np.array_equal(got, want), (D, paths, int((got != want).sum()))
         print("CRC", D, paths, zlib.crc32(got.tobytes()))
+print("SWEEPS", sw)
 print("ok")
 '''
 
@@ -412,12 +414,38 @@ def test_sgm_half_wave_paths_every_d_and_equal_to_the_wave_form():
     # a lane of k_sgm_path_h holds 2 / 4 / 8 disparities (D <= 64 / 128 / 256): every multiple of 16 leaves a different number of
     # dead lanes; W1 = 61 (odd: the last wave of a vertical pass carries one line) and 44; P2 = 30000 (packed u16 sums:
     # minimum + P2 stays below 65536).  RTDM_SGM_HALF=0 runs the round-2 form (one wave per line, 32-bit): same bytes.
+    # RTDM_SGM_SWEEP=0: the six directions that advance a row per step as passes of their own instead of two row-synchronous sweeps.
     import subprocess, sys
     outs = {}
-    for flag in ("2", "1", "0"):
-        env = dict(os.environ, RTDM_SGM_HALF=flag)
+    for flag, sweep in (("2", "1"), ("2", "0"), ("1", "0"), ("0", "0")):
+        env = dict(os.environ, RTDM_SGM_HALF=flag, RTDM_SGM_SWEEP=sweep)
         p = subprocess.run([sys.executable, "-c", _SGM_HALF_CASES % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                            timeout=900, env=env)
-        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (flag, p.stdout[-500:], p.stderr[-3000:])
-        outs[flag] = [ln for ln in p.stdout.splitlines() if ln.startswith("CRC")]
-    assert outs["2"] == outs["0"] == outs["1"] and len(outs["2"]) == 32
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (flag, sweep, p.stdout[-500:], p.stderr[-3000:])
+        outs[flag + sweep] = [ln for ln in p.stdout.splitlines() if ln.startswith("CRC")]
+        assert ("SWEEPS 0" in p.stdout) == (sweep == "0"), (flag, sweep, p.stdout[-300:])
+    assert outs["21"] == outs["20"] == outs["10"] == outs["00"] and len(outs["21"]) == 32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paths,W,H,D,n", [(8, 300, 90, 64, 1), (5, 300, 90, 64, 3), (8, 233, 61, 128, 2), (5, 130, 40, 96, 1), (8, 1280, 200, 128, 2)])
+def test_sgm_row_synchronous_sweep_is_what_runs(pkg, oracle, synth, paths, W, H, D, n):
+    # the down / up directions run as row-synchronous sweeps (k_sgm_sweep: three directions per pass, strips of 32 columns that hand
+    # their edge lines to the neighbours through a tagged ring): one sweep per call in MODE_SGBM, two in MODE_HH, none gives up;
+    # widths that leave a partial last strip, one strip only (W1 = 34 -> two), many strips (36 at 1280), batches
+    import torch
+    Ls, Rs = synth.make_stream(77 + W, n, W, H, D)
+    m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, max_batch=n, paths=paths)
+    dL, dR = torch.from_numpy(Ls).cuda(), torch.from_numpy(Rs).cuda()
+    dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    for rep in range(3):                                     # the ring's tags change with every launch
+        dD.zero_()
+        m.compute_device(dL, dR, dD, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = dD.cpu().numpy()
+        for i in range(n):
+            want = oracle.sgm_compute(Ls[i], Rs[i], numDisparities=D, paths=paths)
+            assert np.array_equal(got[i], want), (rep, i, int((got[i] != want).sum()))
+    sweeps, gave_up = m.pass_stats()
+    m.close()
+    assert sweeps == 3 * (2 if paths == 8 else 1) and not gave_up
