@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 evidence for the StereoSGBM kernels (run on the GPU box): per-kernel time (--kernel-trace --stats) and, in passes
-# of their own, FETCH_SIZE / WRITE_SIZE.  usage: tools/prof_sgm.sh TAG [paths=8]  -> gpurun_out/sgm_prof_TAG/{stats.csv,traffic.json,summary.txt}
+# of their own, FETCH_SIZE / WRITE_SIZE.  usage: tools/prof_sgm.sh TAG [paths=8] [pairs per call=4]  -> gpurun_out/sgm_prof_TAG/{stats.csv,traffic.json,summary.txt}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-x}; PATHS=${2:-8}; N=4; CALLS=3
+TAG=${1:-x}; PATHS=${2:-8}; N=${3:-4}; CALLS=3
 OUT=$R/gpurun_out/sgm_prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/tools/prof_sgm.py $PATHS $N $CALLS > /dev/null 2> $OUT/stats.err
