@@ -17,6 +17,7 @@
 #include "rtdm_device.h"
 
 #include <cstdlib>
+#include <mutex>
 
 namespace rtdm {
 
@@ -584,9 +585,9 @@ __global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t*
 // the low half: single-copy atomic, so a word that shows the expected tag is the expected data -- no fence, no L2 write-back).
 // Every strip needs its neighbours' edge of the PREVIOUS row, which they publish at the start of that row: the strips of a
 // frame advance in lockstep within a row of each other, and a wait is normally already satisfied.  All workgroups of the
-// launch must be resident at once (cooperative launch, grid <= what the device holds; launch_sgm checks); as a second line of
-// defence a wait gives up after ~1 s, sets *abortf and the pass runs to its end without waiting (the host then reports the
-// call as failed and the handle falls back to one pass per direction).
+// launch must be resident at once (grid <= what the device holds, one sweep at a time per process: launch_sweep_c); as a second
+// line of defence a wait gives up after ~1 s, sets *abortf and the pass runs to its end without waiting (the host then
+// reports the call as failed and the handle falls back to one pass per direction).
 static constexpr int SWEEP_RING = 4;                      // rows of edge data kept per (strip, side)
 __device__ __forceinline__ unsigned long long ld_u64_relaxed(const unsigned long long* p)
 { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -955,31 +956,44 @@ static int sweep_capacity(const SGMBuffers& b)
 {
     int& cap = b.sweep_cap[((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 2 + (CPH == 4 ? 1 : 0)];
     if (cap == 0) {
-        int dev = 0, coop = 0, cus = 0, per_cu = 0;
+        int dev = 0, cus = 0, per_cu = 0;
         cap = -1;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop &&
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sgm_sweep<NP2, LAST, CPH>, 256, 0) == hipSuccess && per_cu > 0)
             cap = per_cu * cus;
         (void)hipGetLastError();
     }
     return cap;
 }
+// The workgroups of a sweep wait for each other, so all of them must be resident at once: the grid is no larger than what the
+// device holds, and the sweeps of ONE PROCESS never run side by side -- they all go through one stream per device (two sweeps
+// half resident each would wait for workgroups that cannot start).  The caller's stream and the sweep stream are tied
+// together by the handle's two events; kernels of other streams may share the device with a sweep (they do not wait for it,
+// so they finish and make room).  (hipLaunchCooperativeKernel would promise the residency, but a process that has used it
+// from a thread other than its main one dies in the runtime's exit handlers on ROCm 7.2: tools/sgm_two_threads.py.)
+struct SweepLane { std::mutex mu; hipStream_t s = nullptr; };
+static SweepLane& sweep_lane(int dev) { static SweepLane lanes[64]; return lanes[dev & 63]; }
+
 template <int NP2, bool LAST, int CPH>
 static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
 {
     const int cap = sweep_capacity<NP2, LAST, CPH>(b);
     const int strips = (g.W1 + 8 * CPH - 1) / (8 * CPH);
-    if (cap < strips) return false;
-    int items = n * strips;
+    if (cap < strips || !b.ev_in || !b.ev_out) return false;
+    const int items = n * strips;
     if ((size_t)items * 2 * SWEEP_RING * 32 * NP2 > b.ring_words) return false;
     const int grid = items <= cap ? items : cap / strips * strips;       // the strips of a frame run in the same round
     const uint32_t epoch = (*b.epoch + 1) & 0xffffu;
-    const uint16_t* C = b.C; uint16_t* S = b.S; SGMGeom gg = g; int dyv = dy, p1 = P1, p2 = P2, st = strips, it = items, uq = uniq;
-    unsigned long long* ring = b.ring; int32_t* ab = b.abortf; uint32_t ep = epoch; SgmWin* w = win;
-    void* args[] = {&C, &S, &gg, &dyv, &p1, &p2, &st, &it, &ring, &ab, &ep, &w, &uq};
-    const hipError_t e = hipLaunchCooperativeKernel((const void*)k_sgm_sweep<NP2, LAST, CPH>, dim3(grid), dim3(256), args, 0, stream);
-    if (e != hipSuccess) { (void)hipGetLastError(); b.sweep_cap[((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 2 + (CPH == 4 ? 1 : 0)] = -1; return false; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+    SweepLane& lane = sweep_lane(dev);
+    std::lock_guard<std::mutex> lk(lane.mu);
+    if (!lane.s && hipStreamCreateWithFlags(&lane.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); lane.s = nullptr; return false; }
+    if (hipEventRecord((hipEvent_t)b.ev_in, stream) != hipSuccess || hipStreamWaitEvent(lane.s, (hipEvent_t)b.ev_in, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    hipLaunchKernelGGL((k_sgm_sweep<NP2, LAST, CPH>), dim3(grid), dim3(256), 0, lane.s, b.C, b.S, g, dy, P1, P2, strips, items, b.ring, b.abortf, epoch, win, uniq);
+    // (from here on the caller's stream has to wait for the sweep stream whatever happens, or it would run ahead of it)
+    (void)hipEventRecord((hipEvent_t)b.ev_out, lane.s);
+    (void)hipStreamWaitEvent(stream, (hipEvent_t)b.ev_out, 0);
     ++*b.epoch;
     return true;
 }

@@ -1089,6 +1089,8 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     if (e == hipSuccess) e = hipHostMalloc((void**)&sg->b.abortf, sizeof(int32_t), hipHostMallocMapped);
     if (e == hipSuccess) *sg->b.abortf = 0;
     sg->b.epoch = &sg->sweep_epoch; sg->b.sweep_cap = sg->sweep_cap;
+    if (e == hipSuccess) e = hipEventCreateWithFlags((hipEvent_t*)&sg->b.ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags((hipEvent_t*)&sg->b.ev_out, hipEventDisableTiming);
     if (e != hipSuccess) {
         g_hip_err = std::string("rtdm_sgm_create: ") + hipGetErrorString(e);
         rtdm_sgm_destroy(sg);
@@ -1109,6 +1111,8 @@ void rtdm_sgm_destroy(rtdm_sgm* sg)
     if (sg->b.ovf) (void)hipFree(sg->b.ovf);
     if (sg->b.ring) (void)hipFree(sg->b.ring);
     if (sg->b.abortf) (void)hipHostFree(sg->b.abortf);
+    if (sg->b.ev_in) (void)hipEventDestroy((hipEvent_t)sg->b.ev_in);
+    if (sg->b.ev_out) (void)hipEventDestroy((hipEvent_t)sg->b.ev_out);
     if (sg->hOvf) (void)hipHostFree(sg->hOvf);
     if (sg->stream) (void)hipStreamDestroy(sg->stream);
     delete sg;

@@ -151,6 +151,7 @@ struct SGMBuffers {
     unsigned long long* ring; size_t ring_words;
     int32_t* abortf; uint32_t* epoch;
     int* sweep_cap;          // [12], 0 = not asked yet, < 0 = unusable
+    void *ev_in, *ev_out;    // hipEvent_t: the caller's stream -> the process's sweep stream -> the caller's stream
 };
 size_t sgm_ring_words(int maxW, int D, int max_batch);
 // cost_limit > 0: block costs above it set *b.ovf (the caller reads it back: rtdm_api.hip)

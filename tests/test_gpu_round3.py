@@ -449,3 +449,17 @@ def test_sgm_row_synchronous_sweep_is_what_runs(pkg, oracle, synth, paths, W, H,
     sweeps, gave_up = m.pass_stats()
     m.close()
     assert sweeps == 3 * (2 if paths == 8 else 1) and not gave_up
+
+
+@pytest.mark.gpu
+def test_two_sgm_handles_on_two_threads_and_a_clean_exit():
+    # the sweeps of one process share one stream per device (their workgroups wait for each other, so two sweeps must never be
+    # half resident each); the process must also END cleanly -- with hipLaunchCooperativeKernel called from worker threads it
+    # died in the runtime's exit handlers, which is why the sweep is an ordinary launch (k_sgm.hip: launch_sweep_c)
+    import json, subprocess, sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "sgm_two_threads.py"), "3", "3"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, (p.returncode, p.stdout[-500:], p.stderr[-2000:])
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert not line["errors"] and line["same_as_one_thread"], line
+    assert line["results"]["0"]["pass_stats"] == [6, False] and line["results"]["1"]["pass_stats"] == [3, False], line
