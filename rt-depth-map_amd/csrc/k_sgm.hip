@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
 #pragma unroll
         for (int c = 0; c < CPH; ++c) { m0[c] = m1[c] = m2[c] = 0; for (int r = 0; r < NP2; ++r) L0[c][r] = L1[c][r] = L2[c][r] = NONE; }
         // this row's and the next row's costs: C and S of the half-wave's four columns, requested a row ahead
-        PackW<NP2> cn[CPH], sn[CPH];
+        PackW<NP2> cn[CPH], sn[CPH];                           // (two rows ahead measured slower: 1.16 -> 1.25 ms per pair at 4 pairs per call)
         {
             const int y = dy > 0 ? 0 : H - 1;
 #pragma unroll
@@ -680,6 +680,17 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
             };
 #pragma unroll
             for (int c = 0; c < CPH; ++c) for (int r = 0; r < NP2; ++r) acc[c][r] = sc[c].w[r];
+            // the neighbouring strip's edge of the previous row was published a row ago: ask for it now, look at it after the
+            // row's other lines (a load from the ring is a round trip to memory, ~1 us: as long as a whole row of a lone wave)
+            const bool poll_l = hw == 0 && has_left && !first_row, poll_r = hw == 7 && has_right && !first_row;
+            const unsigned long long* ring_src = (poll_l ? ring_l : ring_r) + ((size_t)((t - 1) & (SWEEP_RING - 1)) * 32 + hl) * NP2;
+            unsigned long long w[NP2];
+#pragma unroll
+            for (int r = 0; r < NP2; ++r) w[r] = 0ull;
+            if (poll_l || poll_r) {
+#pragma unroll
+                for (int r = 0; r < NP2; ++r) w[r] = ld_u64_relaxed(ring_src + r);
+            }
             // (+1, dy): columns CPH - 1 ... 1 take the line of their left neighbour's previous row -- in place in that order
 #pragma unroll
             for (int c = CPH - 1; c >= 1; --c) { sgm_line_step<NP2, true>(L1[c], m1[c], L1[c - 1], m1[c - 1], cc[c].w, first_row, live, hl, P1s, P2s); add_to(c, L1[c]); }
@@ -712,16 +723,13 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
                 if (hw < 7) { for (int r = 0; r < NP2; ++r) inR[r] = xch[par ^ 1][hw + 1][1][r][hl]; inRm = xch[par ^ 1][hw + 1][1][NP2][hl]; }
                 const int wv = threadIdx.x >> 6;
                 if ((wv == 0 && has_left) || (wv == 3 && has_right)) {                 // wave-uniform
-                    const bool poll_l = hw == 0 && has_left, poll_r = hw == 7 && has_right;
-                    const unsigned long long* src = (poll_l ? ring_l : ring_r) + ((size_t)((t - 1) & (SWEEP_RING - 1)) * 32 + hl) * NP2;
                     const uint32_t want = (epoch << 16) | (uint32_t)t;                  // the previous row's tag
-                    unsigned long long w[NP2];
                     bool done = !(poll_l || poll_r) || gave_up;
                     for (int spin = 0;; ++spin) {
                         if (!done) {
                             bool all = true;
 #pragma unroll
-                            for (int r = 0; r < NP2; ++r) { w[r] = ld_u64_relaxed(src + r); all &= (uint32_t)(w[r] >> 32) == want; }
+                            for (int r = 0; r < NP2; ++r) { if (spin) w[r] = ld_u64_relaxed(ring_src + r); all &= (uint32_t)(w[r] >> 32) == want; }
                             done = all;
                         }
                         if (__all(done)) break;
