@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t*
 // Row-synchronous sweep (round 3): the three directions that advance one row per step -- (0, dy), (+1, dy), (-1, dy) -- in ONE
 // pass, so C is read once and S read-modified-written once for the three of them (separate passes: three reads of C, three
 // read-modify-writes of S; with the last sweep deciding the winners, S is not written at all).  A workgroup owns a strip of
-// 8 * CPH columns of one frame and walks its rows; a half-wave owns CPH (4 or 2) neighbouring columns and keeps the previous
+// 8 * CPH columns of one frame and walks its rows; a half-wave owns CPH (4, 2 or 1) neighbouring columns and keeps the previous
 // row's L_r of its 3 * CPH (column, direction) lines in registers.  A diagonal line changes column every row: inside a half-wave that is a
 // register rename (the columns are processed in the order that makes the update in-place), between the half-waves of a
 // workgroup the edge line goes through LDS (double-buffered, one barrier per row), and between neighbouring STRIPS through a
@@ -697,10 +697,24 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
             // (-1, dy): columns 0 ... CPH - 2 take their right neighbour's; a line starts at the frame's last column
 #pragma unroll
             for (int c = 0; c <= CPH - 2; ++c) { sgm_line_step<NP2, true>(L2[c], m2[c], L2[c + 1], m2[c + 1], cc[c].w, first_row || xb + c == W1 - 1, live, hl, P1s, P2s); add_to(c, L2[c]); }
-            // the edges the neighbours will want for their next row: LDS inside the workgroup, the tagged ring between strips
+            // the two lines that enter the half-wave's columns from outside: from the neighbouring half-wave (LDS, written in the
+            // previous row) or, at the strip's ends, from the neighbouring strip (the ring)
+            uint32_t inL[NP2], inR[NP2], inLm = 0, inRm = 0;
 #pragma unroll
-            for (int r = 0; r < NP2; ++r) { xch[par][hw][0][r][hl] = L1[CPH - 1][r]; xch[par][hw][1][r][hl] = L2[0][r]; }
-            xch[par][hw][0][NP2][hl] = m1[CPH - 1]; xch[par][hw][1][NP2][hl] = m2[0];
+            for (int r = 0; r < NP2; ++r) { inL[r] = NONE; inR[r] = NONE; }
+            if (!first_row) {
+                if (hw > 0) { for (int r = 0; r < NP2; ++r) inL[r] = xch[par ^ 1][hw - 1][0][r][hl]; inLm = xch[par ^ 1][hw - 1][0][NP2][hl]; }
+                if (hw < 7) { for (int r = 0; r < NP2; ++r) inR[r] = xch[par ^ 1][hw + 1][1][r][hl]; inRm = xch[par ^ 1][hw + 1][1][NP2][hl]; }
+            }
+            const int wv = threadIdx.x >> 6;
+            const bool ring_l_wave = wv == 0 && has_left && !first_row, ring_r_wave = wv == 3 && has_right && !first_row;   // wave-uniform
+            // the entering lines that do not come through the ring, now: what a strip hands to its neighbours (the (+1, dy) line of
+            // its last column, the (-1, dy) line of its first) never depends on what it is still waiting for from them
+            if (!ring_l_wave) { sgm_line_step<NP2, true>(L1[0], m1[0], inL, inLm, cc[0].w, first_row || xb == 0, live, hl, P1s, P2s); add_to(0, L1[0]); }
+            if (!ring_r_wave) {
+                sgm_line_step<NP2, true>(L2[CPH - 1], m2[CPH - 1], inR, inRm, cc[CPH - 1].w, first_row || xb + CPH - 1 >= W1 - 1, live, hl, P1s, P2s);
+                add_to(CPH - 1, L2[CPH - 1]);
+            }
             const unsigned long long tag = ((unsigned long long)((epoch << 16) | (uint32_t)(t + 1))) << 32;
             if (hw == 7 && has_right) {
 #pragma unroll
@@ -714,45 +728,43 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
             // (0, dy)
 #pragma unroll
             for (int c = 0; c < CPH; ++c) { sgm_line_step<NP2, true>(L0[c], m0[c], L0[c], m0[c], cc[c].w, first_row, live, hl, P1s, P2s); add_to(c, L0[c]); }
-            // the two lines that enter the half-wave's columns from outside
-            uint32_t inL[NP2], inR[NP2], inLm = 0, inRm = 0;
+            if (ring_l_wave || ring_r_wave) {
+                const uint32_t want = (epoch << 16) | (uint32_t)t;                  // the previous row's tag
+                bool done = !(poll_l || poll_r) || gave_up;
+                for (int spin = 0;; ++spin) {
+                    if (!done) {
+                        bool all = true;
 #pragma unroll
-            for (int r = 0; r < NP2; ++r) { inL[r] = NONE; inR[r] = NONE; }
-            if (!first_row) {
-                if (hw > 0) { for (int r = 0; r < NP2; ++r) inL[r] = xch[par ^ 1][hw - 1][0][r][hl]; inLm = xch[par ^ 1][hw - 1][0][NP2][hl]; }
-                if (hw < 7) { for (int r = 0; r < NP2; ++r) inR[r] = xch[par ^ 1][hw + 1][1][r][hl]; inRm = xch[par ^ 1][hw + 1][1][NP2][hl]; }
-                const int wv = threadIdx.x >> 6;
-                if ((wv == 0 && has_left) || (wv == 3 && has_right)) {                 // wave-uniform
-                    const uint32_t want = (epoch << 16) | (uint32_t)t;                  // the previous row's tag
-                    bool done = !(poll_l || poll_r) || gave_up;
-                    for (int spin = 0;; ++spin) {
-                        if (!done) {
-                            bool all = true;
-#pragma unroll
-                            for (int r = 0; r < NP2; ++r) { if (spin) w[r] = ld_u64_relaxed(ring_src + r); all &= (uint32_t)(w[r] >> 32) == want; }
-                            done = all;
-                        }
-                        if (__all(done)) break;
-                        if ((spin & 63) == 63 && (spin > (1 << 20) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                            if (!done) { gave_up = true; __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                            break;
-                        }
-                        __builtin_amdgcn_s_sleep(1);
+                        for (int r = 0; r < NP2; ++r) { if (spin) w[r] = ld_u64_relaxed(ring_src + r); all &= (uint32_t)(w[r] >> 32) == want; }
+                        done = all;
                     }
-                    if (poll_l) { for (int r = 0; r < NP2; ++r) inL[r] = (uint32_t)w[r]; }
-                    if (poll_r) { for (int r = 0; r < NP2; ++r) inR[r] = (uint32_t)w[r]; }
-                    // the minimum of a line that came through the ring is not sent along: take it here (both halves do, one needs it)
-                    uint32_t mmL = NONE, mmR = NONE;
+                    if (__all(done)) break;
+                    if ((spin & 63) == 63 && (spin > (1 << 20) || __hip_atomic_load(abortf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                        if (!done) { gave_up = true; __hip_atomic_store(abortf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (poll_l) { for (int r = 0; r < NP2; ++r) inL[r] = (uint32_t)w[r]; }
+                if (poll_r) { for (int r = 0; r < NP2; ++r) inR[r] = (uint32_t)w[r]; }
+                // the minimum of a line that came through the ring is not sent along: take it here (both halves do, one needs it)
+                uint32_t mmL = NONE, mmR = NONE;
 #pragma unroll
-                    for (int r = 0; r < NP2; ++r) { mmL = sgm_min2(mmL, live ? inL[r] : NONE); mmR = sgm_min2(mmR, live ? inR[r] : NONE); }
-                    const uint32_t hmL = (uint32_t)half_min_i32((int)min(mmL & 0xffffu, mmL >> 16)) * 0x10001u;
-                    const uint32_t hmR = (uint32_t)half_min_i32((int)min(mmR & 0xffffu, mmR >> 16)) * 0x10001u;
-                    if (poll_l) inLm = hmL;
-                    if (poll_r) inRm = hmR;
+                for (int r = 0; r < NP2; ++r) { mmL = sgm_min2(mmL, live ? inL[r] : NONE); mmR = sgm_min2(mmR, live ? inR[r] : NONE); }
+                const uint32_t hmL = (uint32_t)half_min_i32((int)min(mmL & 0xffffu, mmL >> 16)) * 0x10001u;
+                const uint32_t hmR = (uint32_t)half_min_i32((int)min(mmR & 0xffffu, mmR >> 16)) * 0x10001u;
+                if (poll_l) inLm = hmL;
+                if (poll_r) inRm = hmR;
+                if (ring_l_wave) { sgm_line_step<NP2, true>(L1[0], m1[0], inL, inLm, cc[0].w, xb == 0, live, hl, P1s, P2s); add_to(0, L1[0]); }
+                if (ring_r_wave) {
+                    sgm_line_step<NP2, true>(L2[CPH - 1], m2[CPH - 1], inR, inRm, cc[CPH - 1].w, xb + CPH - 1 >= W1 - 1, live, hl, P1s, P2s);
+                    add_to(CPH - 1, L2[CPH - 1]);
                 }
             }
-            sgm_line_step<NP2, true>(L1[0], m1[0], inL, inLm, cc[0].w, first_row || xb == 0, live, hl, P1s, P2s); add_to(0, L1[0]);
-            sgm_line_step<NP2, true>(L2[CPH - 1], m2[CPH - 1], inR, inRm, cc[CPH - 1].w, first_row || xb + CPH - 1 >= W1 - 1, live, hl, P1s, P2s); add_to(CPH - 1, L2[CPH - 1]);
+            // the edge lines for the neighbouring half-waves' next row (final only now when one of them came through the ring)
+#pragma unroll
+            for (int r = 0; r < NP2; ++r) { xch[par][hw][0][r][hl] = L1[CPH - 1][r]; xch[par][hw][1][r][hl] = L2[0][r]; }
+            xch[par][hw][0][NP2][hl] = m1[CPH - 1]; xch[par][hw][1][NP2][hl] = m2[0];
             // S (or the winners)
 #pragma unroll
             for (int c = 0; c < CPH; ++c) {
@@ -955,14 +967,14 @@ static void launch_select(int nch, dim3 grid, size_t lds, hipStream_t stream, co
 }
 
 static inline int sgm_np2(int D) { return D <= 64 ? 1 : (D <= 128 ? 2 : 4); }
-size_t sgm_ring_words(int maxW, int D, int max_batch)                  // sized for the narrow strips (16 columns)
-{ return (size_t)max_batch * ((size_t)(maxW + 15) / 16) * 2 * SWEEP_RING * 32 * sgm_np2(D); }
+size_t sgm_ring_words(int maxW, int D, int max_batch)                  // sized for the narrowest strips (8 columns)
+{ return (size_t)max_batch * ((size_t)(maxW + 7) / 8) * 2 * SWEEP_RING * 32 * sgm_np2(D); }
 
 // One row-synchronous pass over (0, dy), (+1, dy), (-1, dy).  false = not launched (the caller runs the three passes).
 template <int NP2, bool LAST, int CPH>
 static int sweep_capacity(const SGMBuffers& b)
 {
-    int& cap = b.sweep_cap[((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 2 + (CPH == 4 ? 1 : 0)];
+    int& cap = b.sweep_cap[((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 3 + (CPH == 4 ? 2 : CPH - 1)];
     if (cap == 0) {
         int dev = 0, cus = 0, per_cu = 0;
         cap = -1;
@@ -1008,13 +1020,15 @@ static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1
 template <int NP2, bool LAST>
 static bool launch_sweep_t(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
 {
-    // strips of 16 columns (two per half-wave) while their workgroups all fit the device at once: twice the workgroups, and a
-    // frame's rows are a serial chain -- the pass is latency bound until every SIMD holds several waves; 32 columns beyond that
-    // (RTDM_SGM_SWEEP_COLS=2 / 4 fixes the choice: A/B)
+    // the narrowest strips whose workgroups all fit the device at once: 8 columns (one per half-wave), 16, 32 -- a frame's rows
+    // are a serial chain, so the pass is latency bound until every SIMD holds several waves, and the fewer lines a wave carries
+    // the shorter its row; wider strips pay the per-row overhead (barrier, edges, addresses) less often
+    // (RTDM_SGM_SWEEP_COLS=1 / 2 / 4 fixes the choice: A/B)
     static const int cols_env = env_int("RTDM_SGM_SWEEP_COLS", 0);
-    const int cap2 = sweep_capacity<NP2, LAST, 2>(b);
-    const bool narrow = cols_env ? cols_env == 2 : n * ((g.W1 + 15) / 16) <= cap2;
-    if (narrow && launch_sweep_c<NP2, LAST, 2>(g, b, dy, P1, P2, n, win, uniq, stream)) return true;
+    const int cap1 = sweep_capacity<NP2, LAST, 1>(b), cap2 = sweep_capacity<NP2, LAST, 2>(b);
+    const int pick = cols_env ? cols_env : (n * ((g.W1 + 7) / 8) <= cap1 ? 1 : (n * ((g.W1 + 15) / 16) <= cap2 ? 2 : 4));
+    if (pick == 1 && launch_sweep_c<NP2, LAST, 1>(g, b, dy, P1, P2, n, win, uniq, stream)) return true;
+    if (pick <= 2 && launch_sweep_c<NP2, LAST, 2>(g, b, dy, P1, P2, n, win, uniq, stream)) return true;
     return launch_sweep_c<NP2, LAST, 4>(g, b, dy, P1, P2, n, win, uniq, stream);
 }
 static bool launch_sweep(bool last, const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
