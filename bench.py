@@ -15,7 +15,9 @@ After the headline region, on rank 0 and outside `value`:
   * "configs": every other size north_star names -- 320x240 d=32 7x7, 640x480 d=64 9x9, 1280x720 d=128 11x11 + the
     morphological open/close (frame sizes: backup/{320x240,640x480,1280x720}/extrinsics.yml:56-57), and the reference's
     own parameter set d=192 13x13 (main.cpp:134-135, utils/cmdline-parser.cpp:22) -- each on a device-resident batch,
-    >= 20 steps, three frames checked against the CPU oracle, with the oracle timed beside it on every host core;
+    >= 20 steps, three frames checked against the CPU oracle, with the oracle timed beside it on every host core; and
+    BASELINE config 5, the SWSemiGlobalMatcher counterpart (cv::StereoSGBM restated, 1280x720 d=128, 16 pairs per call,
+    MODE_HH and MODE_SGBM, one frame of each checked against the oracle, integer arithmetic: tolerance 0);
   * "single_frame": ms per frame for a caller that hands over one frame per call (estimator.cpp:56), host to host;
   * "cpu_baseline": the oracle (a port: bm-sw.cpp itself needs OpenCV) on the box's host cores, frame-parallel and
     row-striped, the better of the two reported.
@@ -340,6 +342,47 @@ def run_config(cfg, pkg, torch, dev, local_rank, clock_ghz, cpu_budget_s, min_st
     return out
 
 
+def run_sgm_config(pkg, torch, dev, local_rank, batch=16, min_steps=3, min_seconds=0.5, cpu=True):
+    """BASELINE config 5: the SWSemiGlobalMatcher counterpart (cv::StereoSGBM restated) at 1280x720 d=128 blockSize 5 on a
+    device-resident batch: MODE_HH (the "8-path" of the config) and MODE_SGBM (what sgbm-sw.cpp:15 creates), one frame of each
+    checked against the oracle (integer algorithm: tolerance 0), the oracle timed beside it (one thread, one frame)."""
+    import numpy as np
+    from oracle import oracle as orc
+    cd = 128
+    dL = torch.empty((batch, H, W), dtype=torch.uint8, device=dev); dR = torch.empty_like(dL)
+    dD = torch.empty((batch, H, W), dtype=torch.int16, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    pkg.synth_pairs_device(dL, dR, first_frame=0, numDisparities=cd, device=local_rank, stream=st)
+    out = {"key": "config5", "workload": "1280x720 d=128 StereoSGBM blockSize 5 (sgbm-sw.cpp:12-37), %d pairs per call" % batch, "batch": batch,
+           "algorithmic_bytes_per_pair": 4 * W * H, "tolerance": 0}
+    L0, R0 = dL[batch - 1].cpu().numpy(), dR[batch - 1].cpu().numpy()
+    ok = True
+    for paths, name in ((8, "mode_hh_8_paths"), (5, "mode_sgbm_5_paths")):
+        sg = pkg.HIPSemiGlobalMatcher(numOfDisparities=cd, width=W, height=H, max_batch=batch, paths=paths, device=local_rank)
+        def step():
+            sg.compute_device(dL, dR, dD, st)
+        for _ in range(2): step()
+        torch.cuda.synchronize()
+        steps, dt = time_steps(step, torch.cuda.synchronize, min_steps, min_seconds)
+        got = dD[batch - 1].cpu().numpy()
+        rec = {"pairs_per_s": round(batch * steps / dt, 1), "ms_per_pair": round(dt / (batch * steps) * 1e3, 4), "steps": steps}
+        sweeps, gave_up = sg.pass_stats()
+        rec["row_synchronous_sweeps_per_call"] = sweeps // (2 + steps)
+        rec["sweep_gave_up"] = bool(gave_up)
+        if cpu:
+            t0 = time.perf_counter(); want = orc.sgm_compute(L0, R0, numDisparities=cd, paths=paths); tc = time.perf_counter() - t0
+            rec["parity_ok"] = bool(np.array_equal(got, want)); rec["cpu_pairs_per_s_1_thread"] = round(1.0 / tc, 3)
+            ok = ok and rec["parity_ok"]
+        sg.close()
+        out[name] = rec
+    out["pairs_per_s"] = out["mode_hh_8_paths"]["pairs_per_s"]
+    out["ms_per_frame"] = out["mode_hh_8_paths"]["ms_per_pair"]
+    out["frac_of_hbm"] = round(out["pairs_per_s"] * 4 * W * H / 1e9 / HBM_PEAK_GBS, 6)
+    out["parity_ok"] = bool(ok) if cpu else None
+    out["parity_checked_frames"] = 1 if cpu else 0
+    return out
+
+
 def single_frame_latency(pkg, torch, dL, dR, dD, want0, local_rank, stream):
     """"ms/frame" for a caller that hands over ONE frame at a time (the reference's loop, estimator.cpp:56): host to host
     through rtdm_bm_compute -- pageable frames in, pageable map out, PCIe inclusive -- and the device-resident call alone.
@@ -652,7 +695,8 @@ def main():
         torch.cuda.empty_cache()
         cpu_each = 0.0 if args.no_cpu_baseline else (2.5 if world == 1 else 1.5)
         configs = [run_config(c, pkg, torch, dev, local_rank, clock_ghz, cpu_each) for c in CONFIGS]
-        if not all(c["parity_ok"] for c in configs):
+        configs.append(run_sgm_config(pkg, torch, dev, local_rank, cpu=cpu_each > 0))
+        if not all(c["parity_ok"] is not False for c in configs):
             parity_ok = False
             bad = bad + [c["key"] for c in configs if not c["parity_ok"]]
 

@@ -226,10 +226,15 @@ def test_bench_line_carries_every_north_star_size_with_parity():
     out = _bench(["--steps", "3", "--warmup", "2", "--batch", "64"])
     assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["steps"] == 3 and out["parity_ok"] is True
     keys = [c["key"] for c in out["configs"]]
-    assert keys == ["config1", "config2", "config3", "reference_default"]
-    for c in out["configs"]:
+    assert keys == ["config1", "config2", "config3", "reference_default", "config5"]
+    for c in out["configs"][:4]:
         assert c["parity_ok"] is True and c["steps"] >= 20 and c["pairs_per_s"] > 0 and c["cpu_pairs_per_s"] > 0
         assert 0 < c["frac_of_hbm"] < 1 and c["search_kernel"].startswith("fast")
+    sg = out["configs"][4]                                   # the SWSemiGlobalMatcher counterpart: both modes, tolerance 0
+    assert sg["parity_ok"] is True and sg["tolerance"] == 0 and 0 < sg["frac_of_hbm"] < 1
+    for mode, sweeps in (("mode_hh_8_paths", 2), ("mode_sgbm_5_paths", 1)):
+        assert sg[mode]["parity_ok"] is True and sg[mode]["pairs_per_s"] > 0 and sg[mode]["cpu_pairs_per_s_1_thread"] > 0
+        assert sg[mode]["row_synchronous_sweeps_per_call"] == sweeps and sg[mode]["sweep_gave_up"] is False
     assert out["configs"][2]["morph_parity_ok"] is True
     assert out["sustained"]["seconds"] >= 1.5
     assert out["roofline"]["qsad_issue_floor"]["frac_of_floor"] < 1.0
