@@ -903,7 +903,17 @@ int launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12M
         const auto per_half = [&](int nb) { return (size_t)Wp * 4 + 16 + (size_t)nb * Wp * 2; };
         static const int two_env = env_int("RTDM_LR_TWO_ROWS", 1);   // A/B: 0 = one row per workgroup (round 2)
         // row pairs a workgroup walks and merges (1: none -- every pair is left to k_spk_merge_strip, round 3's first form)
-        static const int pairs_env = [] { const int v = env_int("RTDM_LR_PAIRS", 1); return (v == 2 || v == 4 || v == 8) ? v : 1; }();
+        // Two row pairs per workgroup with the vertical contacts inside the block found right here (k_lrcheck_vec<.., NIT = 2> +
+        // k_spk_merge_rec): a frame's contacts are chains of dependent L2 round trips, and with half of them settled from the head
+        // records the merge of one 720p frame takes 12 us instead of 29 (the whole frame 82 -> 66 us of kernels).  Measured against
+        // the packed one-pair form (k_lrcheck_pk + k_spk_merge_strip<4>) over batch sizes (profiles/r03_lr_pairs_ab.txt): frames
+        // up to 1024 wide -- faster or level at every batch size (640x480: -32 % at 12 pairs, -5 % at 128, level at 512); 1280
+        // wide -- faster up to ~16 pairs per call (-9 % for one frame, -23 % at 4), 2-5 % slower beyond, where k_lrcheck_pk
+        // streams and the merge is HBM bound.  RTDM_LR_PAIRS=1 / 2 / 4 / 8 fixes the choice (A/B).
+        static const int pairs_raw = env_int("RTDM_LR_PAIRS", 0);
+        static const long pairs_rows = env_int("RTDM_LR_PAIRS_ROWS", 11520);
+        const int pairs_env = (pairs_raw == 1 || pairs_raw == 2 || pairs_raw == 4 || pairs_raw == 8) ? pairs_raw
+                              : ((g.W <= 1024 || (long)n * nrows <= pairs_rows) ? 2 : 1);
         // two rows per workgroup where the half-wave form wastes fewer lanes than the whole-wave form and fits 512 threads
         const int waves1 = (chunks + 63) / 64, waves2 = (chunks + 31) / 32;
         static const int two_eq = env_int("RTDM_LR_TWO_EQ", 1);      // A/B: 1 = the half-wave form also where it only ties on lanes (W = 320)
@@ -913,7 +923,8 @@ int launch_lrcheck(Plane16W disp, const void* cost, const BMGeom& g, int disp12M
         static const int pk_env = env_int("RTDM_LR_PACKED", 1);      // A/B: 0 = k_lrcheck_vec; NIT from RTDM_LR_PK_PAIRS
         static const int pk_pairs = [] { const int v = env_int("RTDM_LR_PK_PAIRS", 1); return (v == 2 || v == 4 || v == 8) ? v : 1; }();
         const bool pk_ok = pk_env && two_ok_for_pk(g, md, spkDiff) && 2 * per_half(1) + 1024 < 65536;
-        if (two && pk_ok) {
+        const bool contacts_here = two && label && nrows >= 4 && pairs_env > 1;   // k_lrcheck_vec<.., NIT > 1> below
+        if (two && pk_ok && !contacts_here) {
             const dim3 vblock((unsigned)(waves2 * 64));
             const int nit = nrows >= 16 ? pk_pairs : 1;
 #define RTDM_LRP(SPK, NIT) hipLaunchKernelGGL((k_lrcheck_pk<SPK, NIT>), dim3(1, (nrows + 2 * NIT - 1) / (2 * NIT), n), vblock, 2 * per_half(1), stream, disp, \

@@ -358,6 +358,21 @@ def test_border2_equals_border_and_the_oracle():
     assert outs["1"] == outs["0"] and len(outs["1"]) == 14
 
 
+def test_left_right_check_forms_agree_and_match_the_oracle():
+    # the left-right check + speckle init runs as k_lrcheck_vec<.., NIT = 2> (vertical contacts inside two-row-pair blocks found in
+    # the kernel, k_spk_merge_rec) for small launches and narrow frames, as k_lrcheck_pk (packed arithmetic, one row pair) for
+    # large 1280-wide batches; RTDM_LR_PAIRS fixes the form, RTDM_LR_PACKED=0 takes the unpacked one-pair form: same bytes
+    import subprocess, sys
+    outs = {}
+    for name, extra in (("auto", {}), ("pairs1", {"RTDM_LR_PAIRS": "1"}), ("pairs2", {"RTDM_LR_PAIRS": "2"}), ("pairs4", {"RTDM_LR_PAIRS": "4"}),
+                        ("vec1", {"RTDM_LR_PAIRS": "1", "RTDM_LR_PACKED": "0"})):
+        p = subprocess.run([sys.executable, "-c", _BORDER_CASES % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           timeout=900, env=dict(os.environ, **extra))
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (name, p.stderr[-3000:])
+        outs[name] = [ln for ln in p.stdout.splitlines() if ln.startswith("CRC")]
+    assert len(outs["auto"]) == 14 and all(v == outs["auto"] for v in outs.values()), [k for k, v in outs.items() if v != outs["auto"]]
+
+
 # ---- StereoSGBM: any block size (sgbm-sw.cpp:15 passes the caller's through) ---------------------------------------------------
 @pytest.mark.gpu
 @pytest.mark.parametrize("bs,paths", [(19, 8), (21, 5), (4, 8), (18, 5), (25, 8)])
