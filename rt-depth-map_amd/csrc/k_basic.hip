@@ -67,13 +67,41 @@ __global__ __launch_bounds__(256) void k_prefilter8(Plane8 L, Plane8 R, Plane8W 
     *(unsigned long long*)dst = out;                        // plane pitch is a multiple of 64: in bounds
 }
 
+// The unit of work of k_fill_frame (16 pixels of a row outside what the search writes, or one row's run count), also run by the
+// extra workgroups of k_prefilter16<.., true>: a single frame is bound by its launches, not by its kernels.
+struct FillArgs { Plane16W d; int cx0, cx1, vy0, vy1, value; int32_t* rowcnt; int first_block; };
+__device__ __forceinline__ void fill_frame_units(Plane16W d, int W, int H, int cx0, int cx1, int vy0, int vy1, int value, int32_t* rowcnt, int idx, int frame)
+{
+    const int nw = (W + 15) / 16, nl = (cx0 + 15) / 16, nr = (W - cx1 + 15) / 16, nv = vy1 - vy0;
+    const int u0 = nw * vy0, u1 = u0 + nw * (H - vy1), u2 = u1 + nl * nv, u3 = u2 + nr * nv;
+    if (idx >= u3) {
+        idx -= u3;
+        if (rowcnt && idx < H) rowcnt[frame * H + idx] = 0;
+        return;
+    }
+    int y, xs, xe;
+    if (idx < u0)      { y = idx / nw; xs = (idx - y * nw) * 16; xe = W; }
+    else if (idx < u1) { idx -= u0; y = idx / nw; xs = (idx - y * nw) * 16; xe = W; y += vy1; }
+    else if (idx < u2) { idx -= u1; y = idx / nl; xs = (idx - y * nl) * 16; xe = cx0; y += vy0; }
+    else               { idx -= u2; y = idx / nr; xs = cx1 + (idx - y * nr) * 16; xe = W; y += vy0; }
+    int16_t* p = d.base + (size_t)frame * d.frame_e + (size_t)y * d.pitch_e;
+    for (int x = xs; x < min(xs + 16, xe); ++x) p[x] = (int16_t)value;
+}
+
 // Strip variant for 16-byte aligned sources: one thread = 16 columns x RY rows.  Rows stream through registers (each
 // source row is loaded once per strip as ONE 128-bit load; k_prefilter8 issues nine 64-bit loads per 8 output
 // bytes and is bound by the load-issue rate), the bytes left and right of the 16 come from the neighbouring lanes.
-template <int RY>
+template <int RY, bool FILL>
 __global__ __launch_bounds__(256) void k_prefilter16(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp,
-                                                     int W, int H, int cap, int n, int nxb)
+                                                     int W, int H, int cap, int n, int nxb, FillArgs fa)
 {
+    if constexpr (FILL) {
+        if ((int)blockIdx.x >= fa.first_block) {            // the extra workgroups: k_fill_frame's work for frame blockIdx.y
+            if ((int)blockIdx.y < n)
+                fill_frame_units(fa.d, W, H, fa.cx0, fa.cx1, fa.vy0, fa.vy1, fa.value, fa.rowcnt, ((int)blockIdx.x - fa.first_block) * 256 + threadIdx.x, blockIdx.y);
+            return;
+        }
+    }
     const int nstrip = (H + RY - 1) / RY;
     const int idx = blockIdx.x * 256 + threadIdx.x;        // over (strip, 16-byte block)
     const bool inb = idx < nxb * nstrip;
@@ -197,8 +225,10 @@ __global__ __launch_bounds__(256) void k_prefilter1(Plane8 L, Plane8 R, Plane8W 
     O.base[(size_t)f * O.frame + (size_t)y * O.pitch + x] = (uint8_t)v;
 }
 
+// fill != null: the frame fill (launch_fill_frame's arguments) rides in the prefilter's grid where the strip kernel runs, and is a
+// launch of its own before the other forms
 void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, int cap, int n,
-                      hipStream_t stream)
+                      hipStream_t stream, const FillJob* fill)
 {
     const auto al16 = [](const Plane8& p) { return (((size_t)p.base | p.pitch | p.frame) & 15) == 0; };
     const size_t w16 = (size_t)((W + 15) & ~15);
@@ -206,9 +236,22 @@ void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, 
     if (strip16 && al16(L) && al16(R) && L.pitch >= w16 && R.pitch >= w16 && ((size_t)Lp.base & 15) == 0 && ((size_t)Rp.base & 15) == 0) {
         constexpr int RY = 8;
         const int nxb = (W + 15) / 16;
-        hipLaunchKernelGGL(k_prefilter16<RY>, dim3((nxb * ((H + RY - 1) / RY) + 255) / 256, 2 * n), dim3(256), 0, stream, L, R, Lp, Rp, W, H, cap, n, nxb);
+        const int pblocks = (nxb * ((H + RY - 1) / RY) + 255) / 256;
+        FillArgs fa{};
+        static const int fuse_fill = env_int("RTDM_FILL_IN_PREFILTER", 1);      // A/B: 0 = k_fill_frame as a launch of its own
+        if (fill && fuse_fill) {
+            const int nw = (W + 15) / 16, nl = (fill->cx0 + 15) / 16, nr = (W - fill->cx1 + 15) / 16, nv = fill->vy1 - fill->vy0;
+            const int units = nw * fill->vy0 + nw * (H - fill->vy1) + (nl + nr) * nv + (fill->rowcnt ? H : 0);
+            if (units > 0) {
+                fa = FillArgs{fill->disp, fill->cx0, fill->cx1, fill->vy0, fill->vy1, fill->value, fill->rowcnt, pblocks};
+                hipLaunchKernelGGL((k_prefilter16<RY, true>), dim3(pblocks + (units + 255) / 256, 2 * n), dim3(256), 0, stream, L, R, Lp, Rp, W, H, cap, n, nxb, fa);
+                return;
+            }
+        } else if (fill) launch_fill_frame(fill->disp, W, H, fill->cx0, fill->cx1, fill->vy0, fill->vy1, n, fill->value, fill->rowcnt, stream);
+        hipLaunchKernelGGL((k_prefilter16<RY, false>), dim3(pblocks, 2 * n), dim3(256), 0, stream, L, R, Lp, Rp, W, H, cap, n, nxb, fa);
         return;
     }
+    if (fill) launch_fill_frame(fill->disp, W, H, fill->cx0, fill->cx1, fill->vy0, fill->vy1, n, fill->value, fill->rowcnt, stream);
     const auto al8 = [](const Plane8& p) { return (((size_t)p.base | p.pitch | p.frame) & 7) == 0; };
     if (al8(L) && al8(R) && L.pitch >= (size_t)((W + 7) & ~7) && R.pitch >= (size_t)((W + 7) & ~7)) {
         const int nxb = (W + 7) / 8;
@@ -236,21 +279,7 @@ __global__ __launch_bounds__(256) void k_fill16(Plane16W d, int x0, int x1, int 
 // counts of the speckle filter, which the left-right check only writes for the valid rows.
 __global__ __launch_bounds__(256) void k_fill_frame(Plane16W d, int W, int H, int cx0, int cx1, int vy0, int vy1, int value, int32_t* rowcnt)
 {
-    const int nw = (W + 15) / 16, nl = (cx0 + 15) / 16, nr = (W - cx1 + 15) / 16, nv = vy1 - vy0;
-    const int u0 = nw * vy0, u1 = u0 + nw * (H - vy1), u2 = u1 + nl * nv, u3 = u2 + nr * nv;
-    int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= u3) {
-        idx -= u3;
-        if (rowcnt && idx < H) rowcnt[blockIdx.y * H + idx] = 0;
-        return;
-    }
-    int y, xs, xe;
-    if (idx < u0)      { y = idx / nw; xs = (idx - y * nw) * 16; xe = W; }
-    else if (idx < u1) { idx -= u0; y = idx / nw; xs = (idx - y * nw) * 16; xe = W; y += vy1; }
-    else if (idx < u2) { idx -= u1; y = idx / nl; xs = (idx - y * nl) * 16; xe = cx0; y += vy0; }
-    else               { idx -= u2; y = idx / nr; xs = cx1 + (idx - y * nr) * 16; xe = W; y += vy0; }
-    int16_t* p = d.base + (size_t)blockIdx.y * d.frame_e + (size_t)y * d.pitch_e;
-    for (int x = xs; x < min(xs + 16, xe); ++x) p[x] = (int16_t)value;
+    fill_frame_units(d, W, H, cx0, cx1, vy0, vy1, value, rowcnt, blockIdx.x * 256 + threadIdx.x, blockIdx.y);
 }
 
 void launch_fill_frame(Plane16W disp, int W, int H, int cx0, int cx1, int vy0, int vy1, int n, int value, int32_t* rowcnt, hipStream_t stream)
@@ -1076,10 +1105,13 @@ __global__ __launch_bounds__(256) void k_spk_merge(Plane16W disp, int32_t* label
 // arithmetic (neither pixel of the pair starts a run).
 // RS == 1: the pairs are (y, y + 1) for y = y_lo + k * ystep -- what is left when k_lrcheck_vec has merged the pairs inside
 // blocks of ystep rows itself.
-template <int RS, bool COMPACT>
+// REC: the first ra.blocks workgroups do k_spk_merge_rec's work instead (the contacts k_lrcheck_vec<.., NIT > 1> left in the head
+// records: row pairs inside its blocks of rows) -- same queue, same drain, one launch less for a single frame.
+struct MergeRecArgs { int blocks, vy0, nrows, blk, nch; };
+template <int RS, bool COMPACT, bool REC = false>
 __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t* label, const int16_t* headmap, int W, int Ws, int H,
                                                          int y_lo, int npairs, int newVal, int maxDiff, int32_t* size, int maxSize,
-                                                         int ystep)
+                                                         int ystep, MergeRecArgs ra)
 {
     // contacts found by the 256 threads are queued in LDS and united afterwards by the first threads, one union per
     // lane: a union is a chain of dependent global accesses, and a wave with a single busy lane stalls as long as a full one
@@ -1088,10 +1120,40 @@ __global__ __launch_bounds__(256) void k_spk_merge_strip(Plane16W disp, int32_t*
     __shared__ int qn;
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
+    const bool rec_block = REC && (int)blockIdx.x < ra.blocks;            // workgroup-uniform
+    if (rec_block) {
+        // (k_spk_merge_rec's collection) rows r = 1 .. nrows-1 from vy0 with r % blk != 0, numbered densely: j -> r = j + j / (blk - 1) + 1
+        const int inblk = ra.blk - 1, nprs = (ra.nrows / ra.blk) * inblk + max(ra.nrows % ra.blk - 1, 0);
+        const int ridx = blockIdx.x * 256 + threadIdx.x;
+        if (ridx < nprs * ra.nch) {
+            const int j = ridx / ra.nch, chunk = ridx - j * ra.nch;
+            const int y = ra.vy0 + j + j / inblk + 1;
+            const int f = blockIdx.y;
+            const uint32_t* heads = (const uint32_t*)headmap;
+            const size_t rrow = (size_t)(f * H + y) * (Ws >> 3);
+            const uint32_t cb = heads[rrow + chunk];
+            unsigned cand = cb >> 24;
+            if (cand) {
+                const uint32_t ca = heads[rrow - (Ws >> 3) + chunk];
+                const unsigned startA = (ca >> 16) & 0xffu, startB = (cb >> 16) & 0xffu;
+                const int base = (f * H + y) * Ws;
+                while (cand) {
+                    const int k = __builtin_ctz(cand);
+                    cand &= cand - 1;
+                    const unsigned msk = (2u << k) - 1u;
+                    const int na = base - Ws + (int)(ca & 0xffffu) + __builtin_popcount(startA & msk) - 1;
+                    const int nb = base + (int)(cb & 0xffffu) + __builtin_popcount(startB & msk) - 1;
+                    const int slot = atomicAdd(&qn, 1);
+                    if (slot < QCAP) queue[slot] = make_int2(na, nb);
+                    else uf_union(label, na, nb);
+                }
+            }
+        }
+    }
     const int nxb = (W + 7) >> 3;                         // a ragged last chunk reads the plane's padding columns and masks them
     const int nstrips = (npairs + RS - 1) / RS;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const bool inb = idx < nxb * nstrips;
+    const int idx = ((int)blockIdx.x - (REC ? ra.blocks : 0)) * 256 + threadIdx.x;
+    const bool inb = !rec_block && idx < nxb * nstrips;
     const int cidx = inb ? idx : 0;
     const int strip = cidx / nxb, x0 = (cidx % nxb) * 8;
     const int y = y_lo + strip * (RS == 1 ? ystep : RS);
@@ -1256,11 +1318,15 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
     const int first = y_lo + step - 1;
     const int last = min(y_hi, H) - 2;               // last y with y+1 initialised
     const int npairs = last >= first ? (last - first) / step + 1 : 0;
+    MergeRecArgs rec{};
+    static const int fuse_rec = env_int("RTDM_MERGE_REC_FUSED", 1);      // A/B: 0 = k_spk_merge_rec as a launch of its own
     if (compact_heads && step > 1) {               // the contacts inside blocks of `step` rows are in the head records (k_lrcheck_vec<.., NIT > 1>)
         const int nr = min(y_hi, H) - y_lo, inside = (nr / step) * (step - 1) + max(nr % step - 1, 0), nxb = (W + 7) / 8;
-        if (inside > 0)
-            hipLaunchKernelGGL(k_spk_merge_rec, dim3((inside * nxb + 255) / 256, n), block, 0, stream, label, (const uint32_t*)headmap, Ws, H, y_lo, nr, step, nxb,
-                               size, maxSize);
+        if (inside > 0) {
+            if (fuse_rec && npairs > 0) rec = MergeRecArgs{(inside * nxb + 255) / 256, y_lo, nr, step, nxb};   // rides in k_spk_merge_strip<1, true, true> below
+            else hipLaunchKernelGGL(k_spk_merge_rec, dim3((inside * nxb + 255) / 256, n), block, 0, stream, label, (const uint32_t*)headmap, Ws, H, y_lo, nr, step, nxb,
+                                    size, maxSize);
+        }
     }
     if (npairs > 0) {
         const int nxb = (W + 7) / 8;
@@ -1269,8 +1335,9 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
         dim3 grid((nxb * npairs + 255) / 256, n);
         static const int rs = env_int("RTDM_MERGE_STRIP", 4);
         if (compact_heads && step > 1) {           // k_lrcheck_vec<.., NIT > 1> has found the contacts inside blocks of `step` rows
-            dim3 sgrid((nxb * npairs + 255) / 256, n);
-            hipLaunchKernelGGL((k_spk_merge_strip<1, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, step);
+            dim3 sgrid((nxb * npairs + 255) / 256 + rec.blocks, n);
+            if (rec.blocks) hipLaunchKernelGGL((k_spk_merge_strip<1, true, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, step, rec);
+            else hipLaunchKernelGGL((k_spk_merge_strip<1, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, step, MergeRecArgs{});
         } else
         if (compact_heads) {                       // written by k_lrcheck_vec, whose alignment conditions imply `vec`
             // Strips of four row pairs read every row 1.25 times instead of twice -- what a batch wants (the kernel streams the
@@ -1282,15 +1349,15 @@ void launch_speckle(Plane16W disp, int32_t* label, int32_t* size, uint32_t* runs
             while (rsc > 1 && (long)((nxb * ((npairs + rsc - 1) / rsc) + 255) / 256) * n < 1024) rsc >>= 1;
             if (rs_env == 1 || rs_env == 2 || rs_env == 4) rsc = rs_env;
             dim3 sgrid((nxb * ((npairs + rsc - 1) / rsc) + 255) / 256, n);
-            if (rsc == 4)      hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
-            else if (rsc == 2) hipLaunchKernelGGL((k_spk_merge_strip<2, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
-            else               hipLaunchKernelGGL((k_spk_merge_strip<1, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
+            if (rsc == 4)      hipLaunchKernelGGL((k_spk_merge_strip<4, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1, MergeRecArgs{});
+            else if (rsc == 2) hipLaunchKernelGGL((k_spk_merge_strip<2, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1, MergeRecArgs{});
+            else               hipLaunchKernelGGL((k_spk_merge_strip<1, true>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1, MergeRecArgs{});
         } else
         if (vec && step == 1 && rs > 1) {
             const int RSV = rs >= 8 ? 8 : 4;
             dim3 sgrid((nxb * ((npairs + RSV - 1) / RSV) + 255) / 256, n);
-            if (RSV == 8) hipLaunchKernelGGL((k_spk_merge_strip<8, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
-            else          hipLaunchKernelGGL((k_spk_merge_strip<4, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1);
+            if (RSV == 8) hipLaunchKernelGGL((k_spk_merge_strip<8, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1, MergeRecArgs{});
+            else          hipLaunchKernelGGL((k_spk_merge_strip<4, false>), sgrid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, newVal, maxDiff, size, maxSize, 1, MergeRecArgs{});
         } else
         if (vec) hipLaunchKernelGGL(k_spk_merge<true>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);
         else     hipLaunchKernelGGL(k_spk_merge<false>, grid, block, 0, stream, disp, label, headmap, W, Ws, H, first, npairs, step, newVal, maxDiff);

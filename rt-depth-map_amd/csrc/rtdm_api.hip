@@ -456,8 +456,8 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
     *anyout = any;
     if (!any) { launch_fill16(disp, 0, W, 0, H, n, g.filtered, s); return RTDM_OK; }
     // the search kernels write columns [cx0, cx1) of the valid rows; everything else is FILTERED
-    launch_fill_frame(disp, W, H, g.cx0, g.cx1, g.vy0, g.vy1, n, g.filtered,
-                      (p.speckleRange >= 0 && p.speckleWindowSize > 0) ? ln.dRowCnt : nullptr, s);   // (+ the speckle filter's run counts = 0)
+    // (+ the speckle filter's run counts = 0); the fill rides in the prefilter's launch
+    const FillJob fill{disp, g.cx0, g.cx1, g.vy0, g.vy1, g.filtered, (p.speckleRange >= 0 && p.speckleWindowSize > 0) ? ln.dRowCnt : nullptr};
     StageEvent ev;
     const bool fast = fast_search_supported(g);
     bool u16 = false;
@@ -468,7 +468,7 @@ static int chunk_front(rtdm_bm* bm, const Lane& ln, int n, Plane8 L, Plane8 R, i
         bm->variant = ring ? (lpp == 16 ? "fast_ring16_qsad" : lpp == 8 ? "fast_ring8_qsad" : lpp == 4 ? "fast_ring4_qsad" : "fast_ring_qsad") : fast ? "fast_qsad" : (u16 ? "generic_u16" : "generic_u32");
         Plane8W Lp{ln.dLp, bm->ppitch, bm->ppitch * (size_t)H}, Rp{ln.dRp, bm->ppitch, bm->ppitch * (size_t)H};
         stage_begin(bm, RTDM_STAGE_PREFILTER, n, s, &ev);
-        launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s);
+        launch_prefilter(L, R, Lp, Rp, W, H, p.preFilterCap, n, s, &fill);
         stage_end(bm, s, &ev);
         Plane8 Lpr{ln.dLp, Lp.pitch, Lp.frame}, Rpr{ln.dRp, Rp.pitch, Rp.frame};
         stage_begin(bm, RTDM_STAGE_SEARCH, n, s, &ev);

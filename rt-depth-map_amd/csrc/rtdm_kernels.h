@@ -65,8 +65,11 @@ struct Plane16W { int16_t* base; size_t pitch_e, frame_e; };  // strides in elem
 static constexpr int PREFILTER_BIAS = 1;
 
 // K1: x-Sobel prefilter of n left and n right frames in one launch (writes biased values, see above).
+// fill != null: launch_fill_frame's job (below) for the same n frames rides in the same launch where the strip form runs
+// (a single frame is bound by the number of its launches), and is launched by itself before the other forms.
+struct FillJob { Plane16W disp; int cx0, cx1, vy0, vy1, value; int32_t* rowcnt; };
 void launch_prefilter(Plane8 L, Plane8 R, Plane8W Lp, Plane8W Rp, int W, int H, int cap, int n,
-                      hipStream_t stream);
+                      hipStream_t stream, const FillJob* fill = nullptr);
 
 // Fill the rectangle [x0,x1) x [y0,y1) of every disparity frame with `value`.
 void launch_fill16(Plane16W disp, int x0, int x1, int y0, int y1, int n, int value, hipStream_t stream);

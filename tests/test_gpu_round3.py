@@ -365,7 +365,9 @@ def test_left_right_check_forms_agree_and_match_the_oracle():
     import subprocess, sys
     outs = {}
     for name, extra in (("auto", {}), ("pairs1", {"RTDM_LR_PAIRS": "1"}), ("pairs2", {"RTDM_LR_PAIRS": "2"}), ("pairs4", {"RTDM_LR_PAIRS": "4"}),
-                        ("vec1", {"RTDM_LR_PAIRS": "1", "RTDM_LR_PACKED": "0"})):
+                        ("vec1", {"RTDM_LR_PAIRS": "1", "RTDM_LR_PACKED": "0"}),
+                        # the frame fill as a launch of its own instead of inside the prefilter's grid, k_spk_merge_rec likewise
+                        ("unfused", {"RTDM_FILL_IN_PREFILTER": "0", "RTDM_MERGE_REC_FUSED": "0"})):
         p = subprocess.run([sys.executable, "-c", _BORDER_CASES % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                            timeout=900, env=dict(os.environ, **extra))
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (name, p.stderr[-3000:])
