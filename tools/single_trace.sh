@@ -12,10 +12,11 @@ import csv, glob, collections
 f = glob.glob("$OUT/d/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 rows = [r for r in rows if "rtdm" in r["Kernel_Name"]]
-# a call starts with k_fill_frame
+# a call starts with k_fill_frame, or -- since the fill rides in the prefilter's grid -- with the prefilter
 calls, cur = [], []
 for r in rows:
-    if "k_fill_frame" in r["Kernel_Name"] and cur: calls.append(cur); cur = []
+    first = "k_fill_frame" in r["Kernel_Name"] or ("k_prefilter" in r["Kernel_Name"] and not (cur and "k_fill_frame" in cur[-1]["Kernel_Name"]))
+    if first and cur: calls.append(cur); cur = []
     cur.append(r)
 calls.append(cur)
 calls = calls[5:]                     # warm
