@@ -52,6 +52,9 @@
 #ifndef RING_MINREC       // 0: GroupSelect (lane reductions) also where GroupSelectRec (minima in the owner's record) applies: A/B
 #define RING_MINREC 1
 #endif
+#ifndef RING_W3_LIMIT      // two-lane forms: most ring registers a three-wave form may hold.  (32, 13) sits AT 112 and spills ten dwords
+#define RING_W3_LIMIT 112  // at 168 VGPRs -- and is still 9 % faster than as a two-wave form without (111): profiles/r03_ring_spills.txt
+#endif
 #ifndef RING_STATIC_SLOTS // 1: four staging slots where a trip of the row loop is a multiple of four rows: the slot of every unrolled row step
 #define RING_STATIC_SLOTS 1 // is a compile-time constant and all LDS addresses are base + immediate (3-4 VALU per row less)
 #endif
@@ -154,7 +157,7 @@ struct RingCfg {
     // waves per SIMD the register budget is set for: the ring takes W1 * NRL registers, the rest of the kernel about 50
     static constexpr int RING_REGS = W1 * NRL;
     // (tighter bounds spill; eight lanes per pixel = D = 128: the selection records, 17 KB per wave, allow two workgroups per CU)
-    static constexpr int WAVES = LPP >= 8 ? 2 : LPP == 4 ? (RING_REGS <= (MINREC ? 80 : 64) ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : (RING_REGS <= 72 && NRL <= 8) ? 4 : RING_REGS <= 112 ? 3 : 2;
+    static constexpr int WAVES = LPP >= 8 ? 2 : LPP == 4 ? (RING_REGS <= (MINREC ? 80 : 64) ? 4 : (RING_REGS <= 96 && NRL <= 8) ? 3 : 2) : (RING_REGS <= 72 && NRL <= 8) ? 4 : RING_REGS <= RING_W3_LIMIT ? 3 : 2;
     static constexpr int TILE = 4 * PPW;           // four byte phases
     // border-column workgroups may ride in this kernel's grid (small launches): border2_body in every form (it needs no LDS
     // and 52-120 VGPRs for D <= 64); border_body (configurations border2 does not cover) not in the four-wave forms, whose
@@ -163,8 +166,17 @@ struct RingCfg {
     static constexpr bool FUSE_BORDER2 = D <= 192;  // (border2_body<256, 4> needs 261 VGPRs: it stays a launch of its own)
     // LDS read addresses of a row: three registers that advance (3 VALU per row) or recomputed from the slot index (6 VALU,
     // no registers held) -- the latter for the two-lane configurations that sit at their three-wave register limit
-    static constexpr bool ROW_PTRS = !(LPP == 2 && RING_REGS > 88 && RING_REGS <= 112);
+    static constexpr bool ROW_PTRS = !(LPP == 2 && RING_REGS > 88 && WAVES == 3);
 };
+
+// The form with the border-column workgroups in its grid (BORDER: single frames, batches < 16 -- a handful of scheduling rounds,
+// where the occupancy bound buys nothing) is compiled for one wave per SIMD less: border2_body on top of a form that sits at
+// its register limit spilled two dwords ((64, 9, 4) at 128 VGPRs, (192, 15, 8) at 256).
+template <int D, int WS, int LPP, bool BORDER>
+#ifndef RING_BORDER_RELAX   // A/B: 0 = the same bound for both forms (round 3 until then)
+#define RING_BORDER_RELAX 1
+#endif
+struct RingBounds { static constexpr int WAVES = RING_BORDER_RELAX && BORDER && RingCfg<D, WS, LPP>::WAVES > 1 ? RingCfg<D, WS, LPP>::WAVES - 1 : RingCfg<D, WS, LPP>::WAVES; };
 
 template <int D, int WS, int LPP = 2>
 struct RingState { uint64_t P[RingCfg<D, WS, LPP>::W1][RingCfg<D, WS, LPP>::NGL]; };   // only ever indexed with constants: registers
@@ -256,7 +268,7 @@ __device__ __forceinline__ void ring_for_rows(std::integer_sequence<int, R...>, 
 // FUSE: the grid starts with rg.nborder border-column workgroups (an instantiation of its own: with the border body inside,
 // the tile loop of the batch form came out 1.6 % slower)
 template <int D, int WS, int LPP, bool FUSE>
-__global__ __launch_bounds__(256, (RingCfg<D, WS, LPP>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg,
+__global__ __launch_bounds__(256, (RingBounds<D, WS, LPP, FUSE>::WAVES)) void k_search_ring(Plane8 Lp, Plane8 Rp, Plane16W disp, uint16_t* cost, BMGeom g, RingGeom rg,
                                                                                    BorderGeom bg, Border2Geom b2g)
 {
     using C = RingCfg<D, WS, LPP>;
