@@ -624,7 +624,7 @@ __device__ __forceinline__ void sgm_line_step(uint32_t* L, uint32_t& mps, const 
 template <int NP2, bool LAST, int CPH>
 __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* S, SGMGeom g, int dy, int P1, int P2, int strips,
                                                    int items, unsigned long long* ring, int32_t* abortf, uint32_t epoch, SgmWin* win,
-                                                   int uniq)
+                                                   int uniq, int mute_strip)
 {
     __shared__ uint32_t xch[2][8][2][NP2 + 1][32];             // [row parity][half-wave][0: (+1, dy) edge, 1: (-1, dy) edge][pairs, minimum][lane]
     const int lane = threadIdx.x & 63, hl = lane & 31, hw = threadIdx.x >> 5;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
                 add_to(CPH - 1, L2[CPH - 1]);
             }
             const unsigned long long tag = ((unsigned long long)((epoch << 16) | (uint32_t)(t + 1))) << 32;
-            if (hw == 7 && has_right) {
+            if (hw == 7 && has_right && s != mute_strip) {          // (mute_strip >= 0: the test of the give-up path -- that strip never publishes)
 #pragma unroll
                 for (int r = 0; r < NP2; ++r) st_u64_relaxed(ring_me + ((size_t)(t & (SWEEP_RING - 1)) * 32 + hl) * NP2 + r, tag | L1[CPH - 1][r]);
             }
@@ -1010,7 +1010,9 @@ static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1
     std::lock_guard<std::mutex> lk(lane.mu);
     if (!lane.s && hipStreamCreateWithFlags(&lane.s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); lane.s = nullptr; return false; }
     if (hipEventRecord((hipEvent_t)b.ev_in, stream) != hipSuccess || hipStreamWaitEvent(lane.s, (hipEvent_t)b.ev_in, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    hipLaunchKernelGGL((k_sgm_sweep<NP2, LAST, CPH>), dim3(grid), dim3(256), 0, lane.s, b.C, b.S, g, dy, P1, P2, strips, items, b.ring, b.abortf, epoch, win, uniq);
+    // RTDM_SGM_SWEEP_TEST_GIVEUP=1 (tests only): strip 0 never publishes its edge, so its neighbour's wait must run into its bound
+    static const int mute = env_int("RTDM_SGM_SWEEP_TEST_GIVEUP", 0) ? 0 : -1;
+    hipLaunchKernelGGL((k_sgm_sweep<NP2, LAST, CPH>), dim3(grid), dim3(256), 0, lane.s, b.C, b.S, g, dy, P1, P2, strips, items, b.ring, b.abortf, epoch, win, uniq, mute);
     // (from here on the caller's stream has to wait for the sweep stream whatever happens, or it would run ahead of it)
     (void)hipEventRecord((hipEvent_t)b.ev_out, lane.s);
     (void)hipStreamWaitEvent(stream, (hipEvent_t)b.ev_out, 0);

@@ -490,3 +490,44 @@ def test_two_sgm_handles_on_two_threads_and_a_clean_exit():
     line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
     assert not line["errors"] and line["same_as_one_thread"], line
     assert line["results"]["0"]["pass_stats"] == [6, False] and line["results"]["1"]["pass_stats"] == [3, False], line
+
+
+_SGM_GIVEUP = r'''
+import sys, time
+sys.path.insert(0, %r)
+import importlib
+import numpy as np
+pkg = importlib.import_module("rt-depth-map_amd")
+from oracle import oracle as orc
+orc.build()
+W, H, D = 200, 40, 32
+L, R = pkg.synth.make_pair(pkg.synth.STREAM_SEED + 5, W, H, D)
+m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, paths=8)
+t0 = time.time()
+try:
+    m.compute(L, R)
+    print("NOERROR")
+except Exception as e:
+    print("ERROR", str(e)[:160].replace("\n", " "))
+print("SECONDS", round(time.time() - t0, 2), "STATS", m.pass_stats())
+got = m.compute(L, R)                       # from now on: one pass per direction
+print("SECOND", bool(np.array_equal(got, orc.sgm_compute(L, R, numDisparities=D))), m.pass_stats())
+m.close()
+print("ok")
+'''
+
+
+@pytest.mark.gpu
+def test_sgm_sweep_gives_up_instead_of_hanging():
+    # the second line of defence of the row-synchronous sweep: a strip whose neighbour never publishes its edge (forced here:
+    # RTDM_SGM_SWEEP_TEST_GIVEUP) stops waiting after its bound, the pass runs to its end, the call reports the failure ONCE and
+    # the handle computes correct maps with one pass per direction from then on -- nothing hangs
+    import subprocess, sys
+    p = subprocess.run([sys.executable, "-c", _SGM_GIVEUP % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300,
+                       env=dict(os.environ, RTDM_SGM_SWEEP_TEST_GIVEUP="1"))
+    out = p.stdout
+    assert p.returncode == 0 and out.strip().endswith("ok"), (out[-600:], p.stderr[-2000:])
+    assert "ERROR" in out and "gave up" in out and "NOERROR" not in out, out
+    assert "SECOND True" in out and "True)" in out.split("SECOND True")[1], out        # pass_stats(): gave_up stays reported
+    secs = float(out.split("SECONDS")[1].split()[0])
+    assert secs < 60, secs
