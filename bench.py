@@ -571,7 +571,7 @@ def main():
     ap.add_argument("--rccl-stream", type=int, default=0, metavar="FRAMES",
                     help="BASELINE config 4 instead of the headline: rank 0 owns FRAMES pairs, scatter -> compute -> gather "
                          "over torch.distributed (RCCL); reports root-sourced pairs/s")
-    ap.add_argument("--chunk", type=int, default=32, help="--rccl-stream: frames per scatter/gather per rank")
+    ap.add_argument("--chunk", type=int, default=128, help="--rccl-stream: frames per scatter/gather per rank (128: 60 k pairs/s at world size 1, 64: 55 k)")
     args = ap.parse_args()
     if args.headline_only:
         args.no_cpu_baseline = args.no_single_frame = args.no_configs = True
