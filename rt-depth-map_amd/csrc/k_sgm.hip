@@ -485,14 +485,22 @@ __device__ __forceinline__ SgmWin sgm_wta_half(const uint32_t* o, bool live, int
 }
 
 template <int NP2, int PF, bool LAST>
-__global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t* S, SGMGeom g, int dx, int dy, int P1, int P2,
-                                                    int first_dir, int nlines, SgmWin* win, int uniq)
+__global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t* S, SGMGeom g, int dx_, int dy, int P1, int P2,
+                                                    int first_dir, int nlines, SgmWin* win, int uniq, uint16_t* S2)
 {
+    // S2 != null (the two horizontal directions side by side, first_dir = 1): lines [0, nlines) run (dx, 0) and write S, lines
+    // [nlines, 2 nlines) run (-dx, 0) and write S2 -- the first sweep adds the two up.  Same bytes moved as one pass after the
+    // other (the second one's read of S against the sweep's read of S2), but twice the lines in flight: a single pair's 720 rows
+    // are 360 waves on 1024 SIMDs, each a serial chain of W1 steps.
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int line0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
-    if (line0 >= nlines) return;                                  // whole waves only
-    const int line = min(line0 + half, nlines - 1);
-    const bool line_ok = line0 + half < nlines;
+    const int nall = S2 ? 2 * nlines : nlines;
+    if (line0 >= nall) return;                                    // whole waves only
+    const int gline = min(line0 + half, nall - 1);
+    const bool line_ok = line0 + half < nall;
+    const bool second = gline >= nlines;                          // (only with S2)
+    const int line = second ? gline - nlines : gline;
+    const int dx = second ? -dx_ : dx_;
     const int D = g.D, W1 = g.W1, H = g.H;
     int sx, sy;
     if (dy == 0) { sy = line; sx = dx > 0 ? 0 : W1 - 1; }
@@ -509,7 +517,7 @@ __global__ __launch_bounds__(256) void k_sgm_path_h(const uint16_t* C, uint16_t*
     const long stride = ((long)dy * W1 + dx) * D;
     const size_t off0 = (size_t)blockIdx.y * H * W1 * D + ((size_t)sy * W1 + sx) * D + (live ? d0 : 0);
     const uint16_t* cp = C + off0;
-    uint16_t* sp = S + off0;
+    uint16_t* sp = (second ? S2 : S) + off0;
     const uint32_t P1s = (uint32_t)P1 * 0x10001u, P2s = (uint32_t)P2 * 0x10001u;
     PackW<NP2> cr[PF], sr[PF];
 #pragma unroll
@@ -624,7 +632,7 @@ __device__ __forceinline__ void sgm_line_step(uint32_t* L, uint32_t& mps, const 
 template <int NP2, bool LAST, int CPH>
 __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* S, SGMGeom g, int dy, int P1, int P2, int strips,
                                                    int items, unsigned long long* ring, int32_t* abortf, uint32_t epoch, SgmWin* win,
-                                                   int uniq, int mute_strip)
+                                                   int uniq, int mute_strip, const uint16_t* S2)
 {
     __shared__ uint32_t xch[2][8][2][NP2 + 1][32];             // [row parity][half-wave][0: (+1, dy) edge, 1: (-1, dy) edge][pairs, minimum][lane]
     const int lane = threadIdx.x & 63, hl = lane & 31, hw = threadIdx.x >> 5;
@@ -650,26 +658,31 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
 #pragma unroll
         for (int c = 0; c < CPH; ++c) { m0[c] = m1[c] = m2[c] = 0; for (int r = 0; r < NP2; ++r) L0[c][r] = L1[c][r] = L2[c][r] = NONE; }
         // this row's and the next row's costs: C and S of the half-wave's four columns, requested a row ahead
-        PackW<NP2> cn[CPH], sn[CPH];                           // (two rows ahead measured slower: 1.16 -> 1.25 ms per pair at 4 pairs per call)
+        PackW<NP2> cn[CPH], sn[CPH], tn[CPH];                  // (two rows ahead measured slower: 1.16 -> 1.25 ms per pair at 4 pairs per call)
         {
             const int y = dy > 0 ? 0 : H - 1;
 #pragma unroll
             for (int c = 0; c < CPH; ++c) {
                 cn[c] = ld_w<NP2>(C + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);
                 sn[c] = ld_w<NP2>(S + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);
+                if (S2) tn[c] = ld_w<NP2>(S2 + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);   // the other horizontal direction's L_r (k_sgm_path_h)
             }
         }
         for (int t = 0; t < H; ++t) {
             const int y = dy > 0 ? t : H - 1 - t, par = t & 1;
             PackW<NP2> cc[CPH], sc[CPH];
 #pragma unroll
-            for (int c = 0; c < CPH; ++c) { cc[c] = cn[c]; sc[c] = sn[c]; }
+            for (int c = 0; c < CPH; ++c) {
+                cc[c] = cn[c]; sc[c] = sn[c];
+                if (S2) { for (int r = 0; r < NP2; ++r) sc[c].w[r] = sgm_min2(sgm_add2(sc[c].w[r], tn[c].w[r]), 0x7fff7fffu); }   // R5
+            }
             if (t + 1 < H) {
                 const int yn = y + dy;
 #pragma unroll
                 for (int c = 0; c < CPH; ++c) {
                     cn[c] = ld_w<NP2>(C + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
                     sn[c] = ld_w<NP2>(S + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
+                    if (S2) tn[c] = ld_w<NP2>(S2 + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
                 }
             }
             const bool first_row = t == 0;
@@ -966,6 +979,14 @@ static void launch_select(int nch, dim3 grid, size_t lds, hipStream_t stream, co
 #undef RTDM_SEL
 }
 
+// S = min(S + S2, 32767) (R5), two elements per thread: only where the two horizontal directions ran side by side into S and S2
+// and the sweep that was to add them up could not be launched after all
+__global__ __launch_bounds__(256) void k_sgm_add_s2(uint32_t* S, const uint32_t* S2, size_t npairs)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < npairs) S[i] = sgm_min2(sgm_add2(S[i], S2[i]), 0x7fff7fffu);
+}
+
 static inline int sgm_np2(int D) { return D <= 64 ? 1 : (D <= 128 ? 2 : 4); }
 size_t sgm_ring_words(int maxW, int D, int max_batch)                  // sized for the narrowest strips (8 columns)
 { return (size_t)max_batch * ((size_t)(maxW + 7) / 8) * 2 * SWEEP_RING * 32 * sgm_np2(D); }
@@ -995,13 +1016,14 @@ struct SweepLane { std::mutex mu; hipStream_t s = nullptr; };
 static SweepLane& sweep_lane(int dev) { static SweepLane lanes[64]; return lanes[dev & 63]; }
 
 template <int NP2, bool LAST, int CPH>
-static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
+static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream, const uint16_t* S2in, bool probe)
 {
     const int cap = sweep_capacity<NP2, LAST, CPH>(b);
     const int strips = (g.W1 + 8 * CPH - 1) / (8 * CPH);
     if (cap < strips || !b.ev_in || !b.ev_out) return false;
     const int items = n * strips;
     if ((size_t)items * 2 * SWEEP_RING * 32 * NP2 > b.ring_words) return false;
+    if (probe) return true;                                              // (would be launched: the caller plans its passes on that)
     const int grid = items <= cap ? items : cap / strips * strips;       // the strips of a frame run in the same round
     const uint32_t epoch = (*b.epoch + 1) & 0xffffu;
     int dev = 0;
@@ -1012,7 +1034,7 @@ static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1
     if (hipEventRecord((hipEvent_t)b.ev_in, stream) != hipSuccess || hipStreamWaitEvent(lane.s, (hipEvent_t)b.ev_in, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     // RTDM_SGM_SWEEP_TEST_GIVEUP=1 (tests only): strip 0 never publishes its edge, so its neighbour's wait must run into its bound
     static const int mute = env_int("RTDM_SGM_SWEEP_TEST_GIVEUP", 0) ? 0 : -1;
-    hipLaunchKernelGGL((k_sgm_sweep<NP2, LAST, CPH>), dim3(grid), dim3(256), 0, lane.s, b.C, b.S, g, dy, P1, P2, strips, items, b.ring, b.abortf, epoch, win, uniq, mute);
+    hipLaunchKernelGGL((k_sgm_sweep<NP2, LAST, CPH>), dim3(grid), dim3(256), 0, lane.s, b.C, b.S, g, dy, P1, P2, strips, items, b.ring, b.abortf, epoch, win, uniq, mute, S2in);
     // (from here on the caller's stream has to wait for the sweep stream whatever happens, or it would run ahead of it)
     (void)hipEventRecord((hipEvent_t)b.ev_out, lane.s);
     (void)hipStreamWaitEvent(stream, (hipEvent_t)b.ev_out, 0);
@@ -1020,7 +1042,7 @@ static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1
     return true;
 }
 template <int NP2, bool LAST>
-static bool launch_sweep_t(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
+static bool launch_sweep_t(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream, const uint16_t* S2in, bool probe)
 {
     // the narrowest strips whose workgroups all fit the device at once: 8 columns (one per half-wave), 16, 32 -- a frame's rows
     // are a serial chain, so the pass is latency bound until every SIMD holds several waves, and the fewer lines a wave carries
@@ -1029,19 +1051,20 @@ static bool launch_sweep_t(const SGMGeom& g, const SGMBuffers& b, int dy, int P1
     static const int cols_env = env_int("RTDM_SGM_SWEEP_COLS", 0);
     const int cap1 = sweep_capacity<NP2, LAST, 1>(b), cap2 = sweep_capacity<NP2, LAST, 2>(b);
     const int pick = cols_env ? cols_env : (n * ((g.W1 + 7) / 8) <= cap1 ? 1 : (n * ((g.W1 + 15) / 16) <= cap2 ? 2 : 4));
-    if (pick == 1 && launch_sweep_c<NP2, LAST, 1>(g, b, dy, P1, P2, n, win, uniq, stream)) return true;
-    if (pick <= 2 && launch_sweep_c<NP2, LAST, 2>(g, b, dy, P1, P2, n, win, uniq, stream)) return true;
-    return launch_sweep_c<NP2, LAST, 4>(g, b, dy, P1, P2, n, win, uniq, stream);
+    if (pick == 1 && launch_sweep_c<NP2, LAST, 1>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe)) return true;
+    if (pick <= 2 && launch_sweep_c<NP2, LAST, 2>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe)) return true;
+    return launch_sweep_c<NP2, LAST, 4>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
 }
-static bool launch_sweep(bool last, const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream)
+static bool launch_sweep(bool last, const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream,
+                         const uint16_t* S2in = nullptr, bool probe = false)
 {
     switch (sgm_np2(g.D) * 2 + (last ? 1 : 0)) {
-        case 2: return launch_sweep_t<1, false>(g, b, dy, P1, P2, n, win, uniq, stream);
-        case 3: return launch_sweep_t<1, true>(g, b, dy, P1, P2, n, win, uniq, stream);
-        case 4: return launch_sweep_t<2, false>(g, b, dy, P1, P2, n, win, uniq, stream);
-        case 5: return launch_sweep_t<2, true>(g, b, dy, P1, P2, n, win, uniq, stream);
-        case 8: return launch_sweep_t<4, false>(g, b, dy, P1, P2, n, win, uniq, stream);
-        default: return launch_sweep_t<4, true>(g, b, dy, P1, P2, n, win, uniq, stream);
+        case 2: return launch_sweep_t<1, false>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
+        case 3: return launch_sweep_t<1, true>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
+        case 4: return launch_sweep_t<2, false>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
+        case 5: return launch_sweep_t<2, true>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
+        case 8: return launch_sweep_t<4, false>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
+        default: return launch_sweep_t<4, true>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
     }
 }
 
@@ -1081,17 +1104,36 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     static const int sweep_env = env_int("RTDM_SGM_SWEEP", 1);
     bool sweep = sweep_env && half_paths && wave_paths && aligned16 && fuse_select && b.ring && b.abortf && *b.abortf == 0;
     bool swept_down = false, swept_up = false;
+    // RTDM_SGM_DUAL=0 (A/B): the two horizontal directions one after the other (the second adds to S) instead of side by side
+    static const int dual_env = env_int("RTDM_SGM_DUAL", 1);
+    bool s2_pending = false;                         // S2 holds the (-1, 0) direction's L_r and has not been added to S yet
     for (int k = 0; k < 8; ++k) {
         const int dx = dirs[k][0], dy = dirs[k][1];
         if (paths == 5 && dy < 0) continue;          // MODE_SGBM's five directions: nothing runs upwards
+        if (k == 0 && sweep && dual_env && b.S2 && (((size_t)b.S2) & 15) == 0 &&
+            launch_sweep(paths == 5, g, b, 1, P1, P2, n, win, uniq, stream, nullptr, true)) {
+            // both horizontal directions in one launch: (1, 0) -> S, (-1, 0) -> S2; the downward sweep adds the two up
+            const dim3 hgrid((2 * g.H + 7) / 8, n);
+#define RTDM_PATHD(N) hipLaunchKernelGGL((k_sgm_path_h<N, 8, false>), hgrid, blk, 0, stream, b.C, b.S, g, 1, 0, P1, P2, 1, g.H, win, uniq, b.S2)
+            if (g.D <= 64) RTDM_PATHD(1); else if (g.D <= 128) RTDM_PATHD(2); else RTDM_PATHD(4);
+#undef RTDM_PATHD
+            s2_pending = true;
+            continue;
+        }
+        if (k == 1 && s2_pending) continue;
         if (dy != 0) {
             // (0, dy), (+1, dy), (-1, dy) in one row-synchronous pass: -> <- down [up]; the last sweep decides the winners
             bool& done = dy > 0 ? swept_down : swept_up;
             if (done) continue;
             if (sweep && (k == 2 || k == 3)) {
                 const bool last_sweep = paths == 5 || dy < 0;
-                if (launch_sweep(last_sweep, g, b, dy, P1, P2, n, win, uniq, stream)) { done = true; continue; }
+                if (launch_sweep(last_sweep, g, b, dy, P1, P2, n, win, uniq, stream, s2_pending ? b.S2 : nullptr)) { done = true; s2_pending = false; continue; }
                 sweep = false;                       // not launched: this and the remaining directions run as passes of their own
+            }
+            if (s2_pending) {                        // (the sweep that was to add S2 could not be launched)
+                const size_t npairs = (size_t)n * g.H * g.W1 * g.D / 2;
+                hipLaunchKernelGGL(k_sgm_add_s2, dim3((unsigned)((npairs + 255) / 256)), blk, 0, stream, (uint32_t*)b.S, (const uint32_t*)b.S2, npairs);
+                s2_pending = false;
             }
         }
         const int lines = dy == 0 ? g.H : (dx == 0 ? g.W1 : g.W1 + g.H - 1);
@@ -1100,8 +1142,8 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
             // half-wave lines, packed arithmetic: eight lines per workgroup (RTDM_SGM_HALF=1: all passes but the last)
             const dim3 hgrid((lines + 7) / 8, n);
             const int first = k == 0 ? 1 : 0;
-#define RTDM_PATHH(N, P) do { if (last) hipLaunchKernelGGL((k_sgm_path_h<N, P, true>), hgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); \
-                              else hipLaunchKernelGGL((k_sgm_path_h<N, P, false>), hgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq); } while (0)
+#define RTDM_PATHH(N, P) do { if (last) hipLaunchKernelGGL((k_sgm_path_h<N, P, true>), hgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq, (uint16_t*)nullptr); \
+                              else hipLaunchKernelGGL((k_sgm_path_h<N, P, false>), hgrid, blk, 0, stream, b.C, b.S, g, dx, dy, P1, P2, first, lines, win, uniq, (uint16_t*)nullptr); } while (0)
             if (g.D <= 64) RTDM_PATHH(1, 8); else if (g.D <= 128) RTDM_PATHH(2, 8); else RTDM_PATHH(4, 8);
 #undef RTDM_PATHH
         } else if (wave_paths && aligned && g.D <= 256) {

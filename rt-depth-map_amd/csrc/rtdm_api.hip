@@ -1087,6 +1087,7 @@ int rtdm_sgm_create(const rtdm_sgm_params* params, int max_width, int max_height
     if (e == hipSuccess) e = hipMalloc((void**)&sg->b.ring, sg->b.ring_words * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipMemset(sg->b.ring, 0, sg->b.ring_words * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void**)&sg->b.abortf, sizeof(int32_t), hipHostMallocMapped);
+    if (e == hipSuccess && hipMalloc((void**)&sg->b.S2, vol * 2) != hipSuccess) { (void)hipGetLastError(); sg->b.S2 = nullptr; }   // (optional: without it the horizontal passes run one after the other)
     if (e == hipSuccess) *sg->b.abortf = 0;
     sg->b.epoch = &sg->sweep_epoch; sg->b.sweep_cap = sg->sweep_cap;
     if (e == hipSuccess) e = hipEventCreateWithFlags((hipEvent_t*)&sg->b.ev_in, hipEventDisableTiming);
@@ -1110,6 +1111,7 @@ void rtdm_sgm_destroy(rtdm_sgm* sg)
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (sg->b.ovf) (void)hipFree(sg->b.ovf);
     if (sg->b.ring) (void)hipFree(sg->b.ring);
+    if (sg->b.S2) (void)hipFree(sg->b.S2);
     if (sg->b.abortf) (void)hipHostFree(sg->b.abortf);
     if (sg->b.ev_in) (void)hipEventDestroy((hipEvent_t)sg->b.ev_in);
     if (sg->b.ev_out) (void)hipEventDestroy((hipEvent_t)sg->b.ev_out);

@@ -147,6 +147,7 @@ struct SGMBuffers {
     uint8_t *gl, *gr;        // Birchfield-Tomasi bounds of gradient and intensity, 2 x uchar4 per pixel  [n][H][W]
     uint8_t* pix;            // pixel cost                 [n][H][W1][D]
     uint16_t *C, *S;         // block cost, aggregated     [n][H][W1][D]
+    uint16_t* S2;            // the (-1, 0) direction's path costs where the two horizontal directions run side by side (or null)
     int32_t *label, *size, *rowcnt; uint32_t* runs; int16_t* headmap;   // speckle filter workspace
     int32_t* ovf;            // set to 1 by the block-cost kernel where a block cost + P2 passes 32767 (windows > 17 only)
     // row-synchronous sweep (k_sgm_sweep): edge ring between neighbouring strips, give-up flag (page-locked, host readable),
