@@ -78,6 +78,15 @@ __device__ __forceinline__ uint32_t sgm_max2(uint32_t a, uint32_t b)
 { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(sgm_us2, a), __builtin_bit_cast(sgm_us2, b))); }
 __device__ __forceinline__ uint32_t sgm_min2(uint32_t a, uint32_t b)
 { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(sgm_us2, a), __builtin_bit_cast(sgm_us2, b))); }
+// wrapping / saturating packed u16 sums and differences (the path recurrence, the block sums)
+typedef unsigned short sgm_us2w __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t sgm_add2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, (sgm_us2w)(__builtin_bit_cast(sgm_us2w, a) + __builtin_bit_cast(sgm_us2w, b))); }
+__device__ __forceinline__ uint32_t sgm_sub2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, (sgm_us2w)(__builtin_bit_cast(sgm_us2w, a) - __builtin_bit_cast(sgm_us2w, b))); }
+__device__ __forceinline__ uint32_t sgm_adds2(uint32_t a, uint32_t b)
+{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(sgm_us2w, a), __builtin_bit_cast(sgm_us2w, b))); }
+
 // bt_cost of one left pixel (u, u0, u1 replicated into both halves) against two right pixels (low / high half)
 __device__ __forceinline__ uint32_t bt_cost2(uint32_t U, uint32_t U0, uint32_t U1, uint32_t V, uint32_t V0, uint32_t V1)
 { return sgm_min2(sgm_max2(sgm_subs(U, V1), sgm_subs(V0, U)), sgm_max2(sgm_subs(V, U1), sgm_subs(U0, V))); }
@@ -156,6 +165,83 @@ __global__ __launch_bounds__(256) void k_sgm_box(const uint8_t* pix, uint16_t* C
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { sum[j] += h.v[j] - ring[k].v[j]; }
                 ring[k] = h;
+            }
+        }
+    }
+}
+
+// Pixel cost and block sum in ONE kernel for the small windows (R <= 3; D = 16, 32, 64, 128, 256): a workgroup owns a tile of
+// TX = 4 * CG output columns (CG = 256 / (D / 4) columns per pass of its threads) and walks a strip of rows; per source row every
+// thread computes the Birchfield-Tomasi costs of ~4.5 (column, four disparities) items of the tile + halo into LDS (k_sgm_pix's
+// arithmetic, u8), and after one barrier (the tile is double-buffered) sums 2R + 1 of them from LDS for each of its four output
+// columns and slides the vertical window in registers (k_sgm_box's ring, packed u16).  The u8 volume is neither written nor
+// read: 280 MB of HBM traffic per 720p D = 128 pair, and k_sgm_box's 2R + 1 trips to L2 per output are LDS reads.
+template <int R, int DQ>
+__global__ __launch_bounds__(256) void k_sgm_pixbox(const uint2* bl, const uint2* br, uint16_t* C, SGMGeom g, int rows_per_strip)
+{
+    constexpr int CG = 256 / DQ, TX = 4 * CG, TW = TX + 2 * R, NP = (TW + CG - 1) / CG, W1R = 2 * R + 1;
+    __shared__ uint32_t tile[2][TW][DQ];                    // [row parity][tile column][disparity quad]: four u8 pixel costs
+    const int dqi = threadIdx.x % DQ, cg = threadIdx.x / DQ, d = dqi * 4;
+    const int xt0 = blockIdx.x * TX;                        // first output column of the tile (W1 domain)
+    const int f = blockIdx.z;
+    const int y0 = blockIdx.y * rows_per_strip, y1 = min(y0 + rows_per_strip, g.H);
+    const auto rep = [](uint32_t w, int k) -> uint32_t { return ((w >> (8 * k)) & 0xffu) * 0x00010001u; };
+    uint32_t ring[4][W1R][2], sum[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { sum[i][0] = sum[i][1] = 0u; for (int k = 0; k < W1R; ++k) ring[i][k][0] = ring[i][k][1] = 0u; }
+    const int nsrc = (y1 - y0) + 2 * R;                     // source rows y0 - R .. y1 - 1 + R (clamped into the frame)
+    for (int base = 0; base < nsrc; base += W1R) {
+#pragma unroll
+        for (int k = 0; k < W1R; ++k) {
+            const int t = base + k;
+            if (t < nsrc) {                                 // workgroup-uniform
+                const int par = t & 1;
+                const int ysrc = min(max(y0 - R + t, 0), g.H - 1);
+                const size_t row = ((size_t)f * g.H + ysrc) * g.W;
+                // pixel costs of this row's tile columns (+ halo), clamped into [0, W1)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const int tc = cg + p * CG;
+                    if (tc < TW) {
+                        const int xi = min(max(xt0 - R + tc, 0), g.W1 - 1);
+                        const int x = g.x0 + xi, xr = x - (d + g.minD);
+                        const uint2 a = bl[row + x];
+                        uint2 bb[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bb[j] = br[row + xr - j];
+                        const uint32_t Ug = rep(a.x, 0), Ug0 = rep(a.x, 1), Ug1 = rep(a.x, 2), Ur = rep(a.y, 0), Ur0 = rep(a.y, 1), Ur1 = rep(a.y, 2);
+                        uint32_t c2[2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const uint2 lo = bb[2 * q], hi = bb[2 * q + 1];
+                            const uint32_t cgr = bt_cost2(Ug, Ug0, Ug1, __builtin_amdgcn_perm(hi.x, lo.x, 0x0C040C00u), __builtin_amdgcn_perm(hi.x, lo.x, 0x0C050C01u),
+                                                          __builtin_amdgcn_perm(hi.x, lo.x, 0x0C060C02u));
+                            const uint32_t cin = bt_cost2(Ur, Ur0, Ur1, __builtin_amdgcn_perm(hi.y, lo.y, 0x0C040C00u), __builtin_amdgcn_perm(hi.y, lo.y, 0x0C050C01u),
+                                                          __builtin_amdgcn_perm(hi.y, lo.y, 0x0C060C02u));
+                            c2[q] = cgr + ((cin >> 2) & 0x003f003fu);
+                        }
+                        tile[par][tc][dqi] = __builtin_amdgcn_perm(c2[1], c2[0], 0x06040200u);
+                    }
+                }
+                __syncthreads();
+                const int yo = y0 - 2 * R + t;               // the output row whose window this source row completes
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int tcol = cg + i * CG;            // output column xt0 + tcol: tile columns tcol .. tcol + 2R
+                    uint32_t h0 = 0u, h1 = 0u;
+#pragma unroll
+                    for (int q = 0; q < W1R; ++q) {
+                        const uint32_t w = tile[par][tcol + q][dqi];
+                        h0 = sgm_add2(h0, __builtin_amdgcn_perm(0u, w, 0x0C010C00u));    // (d, d + 1) as u16
+                        h1 = sgm_add2(h1, __builtin_amdgcn_perm(0u, w, 0x0C030C02u));    // (d + 2, d + 3)
+                    }
+                    sum[i][0] = sgm_sub2(sgm_add2(sum[i][0], h0), ring[i][k][0]);
+                    sum[i][1] = sgm_sub2(sgm_add2(sum[i][1], h1), ring[i][k][1]);
+                    ring[i][k][0] = h0; ring[i][k][1] = h1;
+                    const int xo = xt0 + tcol;
+                    if (yo >= y0 && xo < g.W1)
+                        *(uint2*)(C + (((size_t)f * g.H + yo) * g.W1 + xo) * g.D + d) = make_uint2(sum[i][0], sum[i][1]);
+                }
             }
         }
     }
@@ -402,14 +488,6 @@ __global__ __launch_bounds__(256) void k_sgm_path_w(const uint16_t* C, uint16_t*
 //   * the two lines of a wave are neighbours in memory for every direction but the horizontal ones (columns x and x + 1 of
 //     one row: 2 * 2 D bytes in one piece), which halves the number of separate pieces the pass asks HBM for.
 // Same values as k_sgm_path_w / k_sgm_path (tests: every D, both modes, against the oracle).
-typedef unsigned short sgm_us2w __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t sgm_add2(uint32_t a, uint32_t b)
-{ return __builtin_bit_cast(uint32_t, (sgm_us2w)(__builtin_bit_cast(sgm_us2w, a) + __builtin_bit_cast(sgm_us2w, b))); }
-__device__ __forceinline__ uint32_t sgm_sub2(uint32_t a, uint32_t b)
-{ return __builtin_bit_cast(uint32_t, (sgm_us2w)(__builtin_bit_cast(sgm_us2w, a) - __builtin_bit_cast(sgm_us2w, b))); }
-__device__ __forceinline__ uint32_t sgm_adds2(uint32_t a, uint32_t b)
-{ return __builtin_bit_cast(uint32_t, __builtin_elementwise_add_sat(__builtin_bit_cast(sgm_us2w, a), __builtin_bit_cast(sgm_us2w, b))); }
-
 template <int NP2> struct PackW { uint32_t w[NP2]; };
 template <int NP2>
 __device__ __forceinline__ PackW<NP2> ld_w(const uint16_t* p)
@@ -1075,6 +1153,20 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
     dim3 blk(256);
     hipLaunchKernelGGL(k_sgm_bounds, dim3((g.W + 255) / 256, g.H, 2 * n), blk, 0, stream, L, R, (uint2*)b.gl, (uint2*)b.gr, g.W, g.H, n);
     const unsigned nxd = (unsigned)(((size_t)g.W1 * (g.D / 4) + 255) / 256);       // D is a multiple of 16
+    // RTDM_SGM_PIXBOX=0 (A/B): pixel cost and block sum as two kernels with the u8 volume between them, for every window
+    static const int pixbox_env = env_int("RTDM_SGM_PIXBOX", 1);
+    const int Rw = blockSize / 2, dq = g.D / 4;
+    const bool pixbox = pixbox_env && Rw <= 3 && (dq == 4 || dq == 8 || dq == 16 || dq == 32 || dq == 64) && !cost_limit;
+    if (pixbox) {
+        const int rps = 48, strips = (g.H + rps - 1) / rps, tx = 4 * (256 / dq);
+        const dim3 pgrid((g.W1 + tx - 1) / tx, strips, n);
+#define RTDM_PB(RR, QQ) hipLaunchKernelGGL((k_sgm_pixbox<RR, QQ>), pgrid, blk, 0, stream, (const uint2*)b.gl, (const uint2*)b.gr, b.C, g, rps)
+#define RTDM_PBR(RR) do { switch (dq) { case 4: RTDM_PB(RR, 4); break; case 8: RTDM_PB(RR, 8); break; case 16: RTDM_PB(RR, 16); break; \
+                                       case 32: RTDM_PB(RR, 32); break; default: RTDM_PB(RR, 64); break; } } while (0)
+        switch (Rw) { case 0: RTDM_PBR(0); break; case 1: RTDM_PBR(1); break; case 2: RTDM_PBR(2); break; default: RTDM_PBR(3); break; }
+#undef RTDM_PBR
+#undef RTDM_PB
+    } else {
     hipLaunchKernelGGL(k_sgm_pix, dim3(nxd, g.H, n), blk, 0, stream, (const uint2*)b.gl, (const uint2*)b.gr, b.pix, g);
     {
         const int rps = 48, strips = (g.H + rps - 1) / rps;
@@ -1085,6 +1177,7 @@ void launch_sgm(Plane8 L, Plane8 R, Plane16W disp, const SGMGeom& g, const SGMBu
             default: hipLaunchKernelGGL(k_sgm_box_any, bgrid, blk, 0, stream, b.pix, b.C, g, blockSize / 2, rps, cost_limit, b.ovf); break;
 #undef RTDM_BOX
         }
+    }
     }
     static const int dirs[8][2] = {{1, 0}, {-1, 0}, {0, 1}, {0, -1}, {1, 1}, {-1, 1}, {1, -1}, {-1, -1}};
     const int threads = (g.D + 63) & ~63;

@@ -442,10 +442,11 @@ def test_sgm_half_wave_paths_every_d_and_equal_to_the_wave_form():
     # RTDM_SGM_SWEEP_COLS = 1 / 2 / 4: strips of 8 / 16 / 32 columns (one, two, four columns per half-wave).
     # The round-2 forms stay reachable too: RTDM_SGM_FUSE_SELECT=0 (k_sgm_select reads S back), RTDM_SGM_WAVE_PATHS=0 (a workgroup per line).
     for flag, sweep, cols in (("2", "1", "1"), ("2", "1", "2"), ("2", "1", "4"), ("2", "0", "0"), ("1", "0", "0"), ("0", "0", "0"),
-                              ("0", "0", "nofuse"), ("0", "0", "nowave"), ("2", "1", "nodual")):
+                              ("0", "0", "nofuse"), ("0", "0", "nowave"), ("2", "1", "nodual"), ("2", "1", "nopixbox")):
         env = dict(os.environ, RTDM_SGM_HALF=flag, RTDM_SGM_SWEEP=sweep, RTDM_SGM_SWEEP_COLS=cols if cols.isdigit() else "0")
         if cols == "nofuse": env["RTDM_SGM_FUSE_SELECT"] = "0"
         if cols == "nowave": env["RTDM_SGM_WAVE_PATHS"] = "0"
+        if cols == "nopixbox": env["RTDM_SGM_PIXBOX"] = "0"       # pixel cost and block sum as two kernels with the u8 volume between them
         if cols == "nodual": env["RTDM_SGM_DUAL"] = "0"           # the two horizontal directions one after the other instead of side by side
         p = subprocess.run([sys.executable, "-c", _SGM_HALF_CASES % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                            timeout=900, env=env)
