@@ -707,7 +707,7 @@ __device__ __forceinline__ void sgm_line_step(uint32_t* L, uint32_t& mps, const 
     mps = (uint32_t)half_min_i32((int)min(mm & 0xffffu, mm >> 16)) * 0x10001u;
 }
 
-template <int NP2, bool LAST, int CPH>
+template <int NP2, bool LAST, int CPH, bool ADD2>
 __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* S, SGMGeom g, int dy, int P1, int P2, int strips,
                                                    int items, unsigned long long* ring, int32_t* abortf, uint32_t epoch, SgmWin* win,
                                                    int uniq, int mute_strip, const uint16_t* S2)
@@ -736,14 +736,14 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
 #pragma unroll
         for (int c = 0; c < CPH; ++c) { m0[c] = m1[c] = m2[c] = 0; for (int r = 0; r < NP2; ++r) L0[c][r] = L1[c][r] = L2[c][r] = NONE; }
         // this row's and the next row's costs: C and S of the half-wave's four columns, requested a row ahead
-        PackW<NP2> cn[CPH], sn[CPH], tn[CPH];                  // (two rows ahead measured slower: 1.16 -> 1.25 ms per pair at 4 pairs per call)
+        PackW<NP2> cn[CPH], sn[CPH], tn[ADD2 ? CPH : 1];                // (two rows ahead measured slower: 1.16 -> 1.25 ms per pair at 4 pairs per call)
         {
             const int y = dy > 0 ? 0 : H - 1;
 #pragma unroll
             for (int c = 0; c < CPH; ++c) {
                 cn[c] = ld_w<NP2>(C + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);
                 sn[c] = ld_w<NP2>(S + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);
-                if (S2) tn[c] = ld_w<NP2>(S2 + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);   // the other horizontal direction's L_r (k_sgm_path_h)
+                if constexpr (ADD2) tn[c] = ld_w<NP2>(S2 + fbase + (size_t)y * rowstride + (size_t)xc[c] * D);   // the other horizontal direction's L_r (k_sgm_path_h)
             }
         }
         for (int t = 0; t < H; ++t) {
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
 #pragma unroll
             for (int c = 0; c < CPH; ++c) {
                 cc[c] = cn[c]; sc[c] = sn[c];
-                if (S2) { for (int r = 0; r < NP2; ++r) sc[c].w[r] = sgm_min2(sgm_add2(sc[c].w[r], tn[c].w[r]), 0x7fff7fffu); }   // R5
+                if constexpr (ADD2) { for (int r = 0; r < NP2; ++r) sc[c].w[r] = sgm_min2(sgm_add2(sc[c].w[r], tn[c].w[r]), 0x7fff7fffu); }   // R5
             }
             if (t + 1 < H) {
                 const int yn = y + dy;
@@ -760,7 +760,7 @@ __global__ __launch_bounds__(256) void k_sgm_sweep(const uint16_t* C, uint16_t* 
                 for (int c = 0; c < CPH; ++c) {
                     cn[c] = ld_w<NP2>(C + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
                     sn[c] = ld_w<NP2>(S + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
-                    if (S2) tn[c] = ld_w<NP2>(S2 + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
+                    if constexpr (ADD2) tn[c] = ld_w<NP2>(S2 + fbase + (size_t)yn * rowstride + (size_t)xc[c] * D);
                 }
             }
             const bool first_row = t == 0;
@@ -1070,15 +1070,15 @@ size_t sgm_ring_words(int maxW, int D, int max_batch)                  // sized 
 { return (size_t)max_batch * ((size_t)(maxW + 7) / 8) * 2 * SWEEP_RING * 32 * sgm_np2(D); }
 
 // One row-synchronous pass over (0, dy), (+1, dy), (-1, dy).  false = not launched (the caller runs the three passes).
-template <int NP2, bool LAST, int CPH>
+template <int NP2, bool LAST, int CPH, bool ADD2>
 static int sweep_capacity(const SGMBuffers& b)
 {
-    int& cap = b.sweep_cap[((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 3 + (CPH == 4 ? 2 : CPH - 1)];
+    int& cap = b.sweep_cap[(((NP2 == 1 ? 0 : (NP2 == 2 ? 1 : 2)) * 2 + (LAST ? 1 : 0)) * 3 + (CPH == 4 ? 2 : CPH - 1)) * 2 + (ADD2 ? 1 : 0)];
     if (cap == 0) {
         int dev = 0, cus = 0, per_cu = 0;
         cap = -1;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sgm_sweep<NP2, LAST, CPH>, 256, 0) == hipSuccess && per_cu > 0)
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sgm_sweep<NP2, LAST, CPH, ADD2>, 256, 0) == hipSuccess && per_cu > 0)
             cap = per_cu * cus;
         (void)hipGetLastError();
     }
@@ -1093,10 +1093,10 @@ static int sweep_capacity(const SGMBuffers& b)
 struct SweepLane { std::mutex mu; hipStream_t s = nullptr; };
 static SweepLane& sweep_lane(int dev) { static SweepLane lanes[64]; return lanes[dev & 63]; }
 
-template <int NP2, bool LAST, int CPH>
+template <int NP2, bool LAST, int CPH, bool ADD2>
 static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream, const uint16_t* S2in, bool probe)
 {
-    const int cap = sweep_capacity<NP2, LAST, CPH>(b);
+    const int cap = sweep_capacity<NP2, LAST, CPH, ADD2>(b);
     const int strips = (g.W1 + 8 * CPH - 1) / (8 * CPH);
     if (cap < strips || !b.ev_in || !b.ev_out) return false;
     const int items = n * strips;
@@ -1112,7 +1112,7 @@ static bool launch_sweep_c(const SGMGeom& g, const SGMBuffers& b, int dy, int P1
     if (hipEventRecord((hipEvent_t)b.ev_in, stream) != hipSuccess || hipStreamWaitEvent(lane.s, (hipEvent_t)b.ev_in, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
     // RTDM_SGM_SWEEP_TEST_GIVEUP=1 (tests only): strip 0 never publishes its edge, so its neighbour's wait must run into its bound
     static const int mute = env_int("RTDM_SGM_SWEEP_TEST_GIVEUP", 0) ? 0 : -1;
-    hipLaunchKernelGGL((k_sgm_sweep<NP2, LAST, CPH>), dim3(grid), dim3(256), 0, lane.s, b.C, b.S, g, dy, P1, P2, strips, items, b.ring, b.abortf, epoch, win, uniq, mute, S2in);
+    hipLaunchKernelGGL((k_sgm_sweep<NP2, LAST, CPH, ADD2>), dim3(grid), dim3(256), 0, lane.s, b.C, b.S, g, dy, P1, P2, strips, items, b.ring, b.abortf, epoch, win, uniq, mute, S2in);
     // (from here on the caller's stream has to wait for the sweep stream whatever happens, or it would run ahead of it)
     (void)hipEventRecord((hipEvent_t)b.ev_out, lane.s);
     (void)hipStreamWaitEvent(stream, (hipEvent_t)b.ev_out, 0);
@@ -1127,11 +1127,18 @@ static bool launch_sweep_t(const SGMGeom& g, const SGMBuffers& b, int dy, int P1
     // the shorter its row; wider strips pay the per-row overhead (barrier, edges, addresses) less often
     // (RTDM_SGM_SWEEP_COLS=1 / 2 / 4 fixes the choice: A/B)
     static const int cols_env = env_int("RTDM_SGM_SWEEP_COLS", 0);
-    const int cap1 = sweep_capacity<NP2, LAST, 1>(b), cap2 = sweep_capacity<NP2, LAST, 2>(b);
+    // (the instantiation that also adds S2 -- the first sweep after the side-by-side horizontal directions -- holds one more
+    // volume's row in registers: a template parameter, so that the other sweep keeps its occupancy)
+    const bool add2 = S2in != nullptr || (probe && b.S2 != nullptr);
+    const int cap1 = add2 ? sweep_capacity<NP2, LAST, 1, true>(b) : sweep_capacity<NP2, LAST, 1, false>(b);
+    const int cap2 = add2 ? sweep_capacity<NP2, LAST, 2, true>(b) : sweep_capacity<NP2, LAST, 2, false>(b);
     const int pick = cols_env ? cols_env : (n * ((g.W1 + 7) / 8) <= cap1 ? 1 : (n * ((g.W1 + 15) / 16) <= cap2 ? 2 : 4));
-    if (pick == 1 && launch_sweep_c<NP2, LAST, 1>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe)) return true;
-    if (pick <= 2 && launch_sweep_c<NP2, LAST, 2>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe)) return true;
-    return launch_sweep_c<NP2, LAST, 4>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe);
+#define RTDM_SWC(CC) (add2 ? launch_sweep_c<NP2, LAST, CC, true>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe) \
+                           : launch_sweep_c<NP2, LAST, CC, false>(g, b, dy, P1, P2, n, win, uniq, stream, S2in, probe))
+    if (pick == 1 && RTDM_SWC(1)) return true;
+    if (pick <= 2 && RTDM_SWC(2)) return true;
+    return RTDM_SWC(4);
+#undef RTDM_SWC
 }
 static bool launch_sweep(bool last, const SGMGeom& g, const SGMBuffers& b, int dy, int P1, int P2, int n, SgmWin* win, int uniq, hipStream_t stream,
                          const uint16_t* S2in = nullptr, bool probe = false)

@@ -1007,7 +1007,7 @@ struct rtdm_sgm {
     int cost_limit;                // > 0 (windows > 17 at P2 = 2400): a block cost above it would wrap the library's 16-bit path costs
     int32_t* hOvf;                 // page-locked copy of b.ovf
     uint32_t sweep_epoch;          // launches of k_sgm_sweep (tags of its edge ring)
-    int sweep_cap[18];             // workgroups the device holds at once, per instantiation (0 = not asked yet)
+    int sweep_cap[36];             // workgroups the device holds at once, per instantiation (0 = not asked yet)
     bool sweep_reported;           // a give-up of the sweep has been returned to the caller
 };
 

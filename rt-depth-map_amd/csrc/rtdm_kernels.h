@@ -154,7 +154,7 @@ struct SGMBuffers {
     // the handle's launch counter (tags of the ring words), how many workgroups the device holds at once per instantiation
     unsigned long long* ring; size_t ring_words;
     int32_t* abortf; uint32_t* epoch;
-    int* sweep_cap;          // [18], 0 = not asked yet, < 0 = unusable
+    int* sweep_cap;          // [36], 0 = not asked yet, < 0 = unusable
     void *ev_in, *ev_out;    // hipEvent_t: the caller's stream -> the process's sweep stream -> the caller's stream
 };
 size_t sgm_ring_words(int maxW, int D, int max_batch);
