@@ -7,12 +7,16 @@
 //
 //   k_sgm_bounds x-Sobel (vertical edge replication) clipped to +-15, + 15, and the BT bounds of it and of the
 //                intensity (border columns overwritten with 15, R1), per pixel          (HBM bound)
-//   k_sgm_pix    Birchfield-Tomasi pixel cost, gradient + (intensity >> 2) -> u8      (thread = 4 d)
-//   k_sgm_box    blockSize x blockSize sum with clamped coordinates -> C (u16)
-//   k_sgm_path_w one WAVE per path line: L_r recurrence, S = min(S + L_r, 32767) (R5); launched once per direction
-//   k_sgm_select one workgroup per row: winner-take-all, uniqueness, quadratic sub-pixel, left-right check on the
-//                integer winners (LDS votes, right-most voter wins ties: R7)
+//   k_sgm_pixbox Birchfield-Tomasi pixel cost (gradient + (intensity >> 2), u8, kept in LDS) and the blockSize x blockSize sum
+//                with clamped coordinates -> C (u16), windows <= 7; larger windows: k_sgm_pix (u8 volume) + k_sgm_box / _any
+//   k_sgm_path_h one HALF-WAVE per path line, packed u16 recurrence: L_r, S = min(S + L_r, 32767) (R5); the two horizontal
+//                directions in one launch (-> S, <- S2)
+//   k_sgm_sweep  the three directions that advance a row per step in one row-synchronous pass (adds S2; the last sweep decides
+//                the winners: wave minimum, uniqueness, quadratic sub-pixel) -> 8 bytes per pixel
+//   k_sgm_lrfinal one workgroup per row: the votes of the integer winners (LDS, right-most voter wins ties: R7) and the
+//                always-on left-right check (R9)
 //   k_sgm_median 3x3 median with clamped coordinates (R10) + the speckle filter's per-row init
+//   (round-2 forms kept for A/B: k_sgm_path / k_sgm_path_w, one workgroup / one wave per line and direction; k_sgm_select)
 #include "rtdm_kernels.h"
 #include "rtdm_device.h"
 
