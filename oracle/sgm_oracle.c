@@ -211,7 +211,8 @@ void orc_sgm_select(const uint16_t* S, int W, int H, int D, int minD, int unique
             const uint16_t* s = S + ((size_t)y * W1 + (x - minX1)) * D;
             int mins = SHRT_MAX, bd = -1;
             for (int d = 0; d < D; ++d) if (s[d] < mins) { mins = s[d]; bd = d; }
-            if (bd < 0) continue;            /* every S saturated: the library's bestDisp stays -1; not reachable below the cap */
+            if (bd < 0) continue;            /* every S saturated at 32767 (a large P2, 8 paths): the library's bestDisp stays -1, it
+                                              * casts no vote and what it writes, (-1 + minD) * 16, IS the invalid value */
             int d;
             for (d = 0; d < D; ++d)
                 if ((int)s[d] * (100 - uniq) < mins * 100 && iabs(bd - d) > 1) break;

@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_sgm_path_w(const uint16_t* C, uint16_t*
                 const int xi = sx + step * dx, yy = sy + step * dy;
                 SgmWin wv;
                 wv.d16 = (int16_t)((g.minD - 1) * 16); wv.bd = (int16_t)(g.minD - 1); wv.mins = 0; wv.pad = 0;
-                if (!__any(hit)) {                                    // wave-uniform
+                if (!__any(hit) && mins < 32767) {                    // wave-uniform (mins = 32767: every cost saturated, the library finds no winner)
                     const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
                     int s_p = 0, s_n = 0;
 #pragma unroll
@@ -541,7 +541,9 @@ __device__ __forceinline__ SgmWin sgm_wta_half(const uint32_t* o, bool live, int
 #pragma unroll
     for (int j = 0; j < 2 * NP2; ++j) hit |= (unsigned)(d0 + j - bd + 1) > 2u && v[j] * (100 - uniq) < lim;
     const unsigned long long hits = __ballot(hit && live);
-    const bool rejected = ((lane & 32) ? (uint32_t)(hits >> 32) : (uint32_t)hits) != 0u;
+    // every aggregated cost saturated (R5) at 32767: the library's search for a cost BELOW its initial SHRT_MAX finds none, its
+    // bestDisp stays -1 and what it writes is the invalid value -- no winner, no vote (reachable with a large P2 and 8 paths)
+    const bool rejected = ((lane & 32) ? (uint32_t)(hits >> 32) : (uint32_t)hits) != 0u || mins >= 32767;
     // S[d* +- 1]: the pair that holds it, from the lane that holds it (ds_bpermute, no LDS memory involved)
     const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
     constexpr int LG = NP2 == 1 ? 1 : (NP2 == 2 ? 2 : 3);         // log2 of the disparities per lane
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(256) void k_sgm_select(const uint16_t* S, Plane16W 
             const int d = lane + 64 * c;
             hit |= d < D && abs(d - bd) > 1 && v[c] * (100 - uniq) < lim;
         }
-        if (__any(hit)) continue;                             // wave-uniform
+        if (__any(hit) || mins >= 32767) continue;            // wave-uniform (mins = 32767: every cost saturated, the library finds no winner)
         const int ip = min(bd + 1, D - 1), in = max(bd - 1, 0);
         int sp = 0, sn = 0;
 #pragma unroll

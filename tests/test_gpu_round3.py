@@ -533,3 +533,20 @@ def test_sgm_sweep_gives_up_instead_of_hanging():
     assert "SECOND True" in out and "True)" in out.split("SECOND True")[1], out        # pass_stats(): gave_up stays reported
     secs = float(out.split("SECONDS")[1].split()[0])
     assert secs < 60, secs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("paths", [8, 5])
+def test_sgm_every_cost_saturated_is_no_winner(pkg, oracle, synth, paths):
+    # a large P2 and eight paths drive the saturating sum (R5) to 32767 at EVERY disparity of some pixels: the library's search
+    # for a cost below its initial SHRT_MAX then finds none (bestDisp stays -1: the invalid value, no vote).  Found by
+    # tools/soak_sgm.py (seed 500155): the device took disparity 0 there, in every form since round 2.
+    W, H, D = 88, 67, 48
+    kw = dict(blockSize=11, uniquenessRatio=0, speckleWindowSize=20, speckleRange=2, disp12MaxDiff=1, P1=600, P2=20000, paths=paths)
+    Ls, Rs = synth.make_stream(155, 1, W, H, D)
+    L, R = (Ls[0] // 32 * 32).astype(np.uint8), (Rs[0] // 32 * 32).astype(np.uint8)
+    want = oracle.sgm_compute(L, R, numDisparities=D, **kw)
+    m = pkg.HIPSemiGlobalMatcher(numOfDisparities=D, width=W, height=H, **kw)
+    got = m.compute(L, R)
+    m.close()
+    assert np.array_equal(got, want), int((got != want).sum())
