@@ -27,5 +27,32 @@ for seed in range(first, first + count):
         except Exception:          # noqa: BLE001
             bad += 1
             print("ERROR", name, "seed", seed, traceback.format_exc()[-400:], flush=True)
-print("checked", count, "seeds x (objects, morphology), mismatches", bad, flush=True)
+# rectification: random frame sizes, maps that point far outside / at the edges / at every fractional offset, random crops, batches
+for seed in range(first, first + max(1, count // 2)):
+    if (seed - first) % 50 == 0: print("rectify case", seed - first, "mismatches so far", bad, flush=True)
+    rng = np.random.default_rng(seed + 31337)
+    W, H = int(rng.integers(1, 300)), int(rng.integers(1, 160))
+    maps = []
+    for k in range(2):
+        maps.append(np.stack([rng.integers(-4, W + 3, (H, W)), rng.integers(-4, H + 3, (H, W))], -1).astype(np.int16))
+        maps.append(rng.integers(0, 1024, (H, W)).astype(np.uint16))
+    n = int(rng.choice([1, 2, 3]))
+    L = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8); R = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    rw, rh = int(rng.integers(1, W + 1)), int(rng.integers(1, H + 1))
+    roi = (int(rng.integers(0, W - rw + 1)), int(rng.integers(0, H - rh + 1)), rw, rh)
+    try:
+        r = pkg.HIPRectifier(*maps, roi=roi, max_batch=n)
+        dl = torch.empty((n, roi[3], roi[2]), dtype=torch.uint8, device="cuda"); dr = torch.empty_like(dl)
+        r.gray_device(torch.from_numpy(L).cuda(), torch.from_numpy(R).cuda(), dl, dr)
+        torch.cuda.synchronize()
+        ok = all(np.array_equal(dl[i].cpu().numpy(), orc.rectify_gray(L[i], maps[0], maps[1], roi)) and
+                 np.array_equal(dr[i].cpu().numpy(), orc.rectify_gray(R[i], maps[2], maps[3], roi)) for i in range(n))
+        ok = ok and np.array_equal(r.rgb(L[0], 1), orc.rectify_rgb(L[0], maps[2], maps[3], roi))
+        r.close()
+        if not ok:
+            bad += 1; print("MISMATCH rectify seed", seed, W, H, n, roi, flush=True)
+    except Exception:          # noqa: BLE001
+        bad += 1
+        print("ERROR rectify seed", seed, W, H, n, roi, traceback.format_exc()[-400:], flush=True)
+print("checked", count, "seeds x (objects, morphology) +", max(1, count // 2), "x rectification, mismatches", bad, flush=True)
 sys.exit(1 if bad else 0)
