@@ -12,6 +12,7 @@ from oracle import oracle as orc
 orc.build()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+wide = len(sys.argv) > 3 and sys.argv[3] == "wide"       # python tools/soak_sgm.py FIRST COUNT wide: frames 640-1280 wide
 st = torch.cuda.current_stream().cuda_stream
 bad = 0
 sweeps = 0
@@ -24,6 +25,8 @@ for seed in range(first, first + count):
     W = D + abs(minD) + int(rng.choice([9, 17, 33, 40, 64, 65, 97, 130, 200, 333]))
     H = int(rng.integers(3, 70))
     n = int(rng.choice([1, 1, 2, 3, 5]))
+    if wide:                                     # many strips per frame, batches large enough to change the strip width
+        W = int(rng.choice([640, 901, 1280, 1279])); H = int(rng.integers(8, 48)); n = int(rng.choice([1, 2, 6, 17]))
     kw = dict(blockSize=bs, minDisparity=minD, uniquenessRatio=int(rng.choice([10, 0, 25, -1])),
               speckleWindowSize=int(rng.choice([100, 0, 20])), speckleRange=int(rng.choice([32, 1, 2])),
               disp12MaxDiff=int(rng.choice([1, -1, 2])), P1=int(rng.choice([600, 8, 100, 0])),
