@@ -54,5 +54,28 @@ for seed in range(first, first + max(1, count // 2)):
     except Exception:          # noqa: BLE001
         bad += 1
         print("ERROR rectify seed", seed, W, H, n, roi, traceback.format_exc()[-400:], flush=True)
-print("checked", count, "seeds x (objects, morphology) +", max(1, count // 2), "x rectification, mismatches", bad, flush=True)
+# depth statistics behind the matcher (/16 + reprojection + per-region mean Z): random disparity maps (with invalid pixels), Q, masks, regions
+for seed in range(first, first + max(1, count // 2)):
+    if (seed - first) % 50 == 0: print("depth case", seed - first, "mismatches so far", bad, flush=True)
+    rng = np.random.default_rng(seed + 4242)
+    W, H = int(rng.integers(8, 400)), int(rng.integers(4, 200))
+    d = rng.integers(-16, 64 * 16, (H, W)).astype(np.int16)
+    d[rng.random((H, W)) < 0.3] = -16                                   # FILTERED
+    d[rng.random((H, W)) < 0.05] = 0                                    # disparity 0: Z = inf in the library, skipped
+    mask = ((rng.random((H, W)) < float(rng.choice([0.2, 0.6, 1.0]))) * 255).astype(np.uint8)
+    Q = np.array([[1, 0, 0, -W / 2 - 0.3], [0, 1, 0, -H / 2 - 0.8], [0, 0, 0, float(rng.uniform(100, 900))], [0, 0, 1 / float(rng.uniform(1, 20)), float(rng.choice([0.0, 0.0, 0.37]))]])
+    regions = []
+    for _ in range(int(rng.integers(1, 7))):
+        rw, rh = int(rng.integers(1, W + 1)), int(rng.integers(0, H + 1))
+        regions.append((int(rng.integers(0, W - rw + 1)), int(rng.integers(0, H - max(rh, 1) + 1)), rw, rh))
+    unit = float(rng.choice([25.0, 1.0, 108.0]))
+    try:
+        mean, cnt = pkg.depth_stats_device(torch.from_numpy(d).cuda(), Q, torch.from_numpy(mask).cuda(), regions, unit)
+        wm, wc = orc.depth_stats(d, Q, mask, regions, unit)
+        if not (np.array_equal(cnt, wc) and np.allclose(mean, wm, rtol=1e-9, atol=0, equal_nan=True)):
+            bad += 1; print("MISMATCH depth seed", seed, W, H, regions, list(cnt), list(wc), list(mean), list(wm), flush=True)
+    except Exception:          # noqa: BLE001
+        bad += 1
+        print("ERROR depth seed", seed, W, H, regions, traceback.format_exc()[-500:], flush=True)
+print("checked", count, "seeds x (objects, morphology) +", max(1, count // 2), "x (rectification, depth statistics), mismatches", bad, flush=True)
 sys.exit(1 if bad else 0)
