@@ -13,6 +13,7 @@ orc.build()
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 300
 wide = len(sys.argv) > 3 and sys.argv[3] == "wide"       # python tools/soak_sgm.py FIRST COUNT wide: frames 640-1280 wide
+big = len(sys.argv) > 3 and sys.argv[3] == "big"         # python tools/soak_sgm.py FIRST COUNT big: windows > 17
 st = torch.cuda.current_stream().cuda_stream
 bad = 0
 sweeps = 0
@@ -31,6 +32,8 @@ for seed in range(first, first + count):
               speckleWindowSize=int(rng.choice([100, 0, 20])), speckleRange=int(rng.choice([32, 1, 2])),
               disp12MaxDiff=int(rng.choice([1, -1, 2])), P1=int(rng.choice([600, 8, 100, 0])),
               P2=int(rng.choice([2400, 700, 3000, 0, 20000])), paths=int(rng.choice([8, 5])))
+    if big:                                      # windows > 17: k_sgm_box_any with the cost check; a frame whose costs would wrap is refused by both
+        kw["blockSize"] = int(rng.choice([19, 21, 25, 18, 33]))
     Ls, Rs = pkg.synth.make_stream(seed % 100000, n, W, H, D)
     if rng.random() < 0.2:                       # plateaus: many exact ties
         Ls = (Ls // 32 * 32).astype(np.uint8); Rs = (Rs // 32 * 32).astype(np.uint8)
@@ -45,10 +48,23 @@ for seed in range(first, first + count):
         continue
     dL, dR = torch.from_numpy(Ls).cuda(), torch.from_numpy(Rs).cuda()
     dD = torch.empty((n, H, W), dtype=torch.int16, device="cuda")
+    refused = False
     for rep in range(2):
         dD.fill_(12345)
-        m.compute_device(dL, dR, dD, st)
+        try:
+            m.compute_device(dL, dR, dD, st)
+        except Exception as e:       # noqa: BLE001 -- a frame whose block cost + P2 passes 32767: the oracle must refuse it as well
+            refused = True
+            torch.cuda.synchronize()
+            try:
+                for i in range(n): orc.sgm_compute(Ls[i], Rs[i], numDisparities=D, **kw)
+                bad += 1; print("FRAME REFUSED ONLY BY THE DEVICE seed", seed, W, H, D, n, kw, repr(e)[:80])
+            except ValueError:
+                pass
+            break
         torch.cuda.synchronize()
+    if refused:
+        m.close(); continue
     got = dD.cpu().numpy()
     sw, gave_up = m.pass_stats()
     sweeps += sw
@@ -56,7 +72,10 @@ for seed in range(first, first + count):
     if gave_up:
         bad += 1; print("SWEEP GAVE UP seed", seed, W, H, D, n, kw)
     for i in range(n):
-        want = orc.sgm_compute(Ls[i], Rs[i], numDisparities=D, **kw)
+        try:
+            want = orc.sgm_compute(Ls[i], Rs[i], numDisparities=D, **kw)
+        except ValueError:
+            bad += 1; print("FRAME REFUSED ONLY BY THE ORACLE seed", seed, W, H, D, n, i, kw); continue
         if not np.array_equal(got[i], want):
             bad += 1
             print("MISMATCH seed", seed, W, H, D, n, i, kw, int((got[i] != want).sum()))
